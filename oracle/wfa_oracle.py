@@ -1,0 +1,354 @@
+"""CPU oracle for the per-record waveform hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy/scipy restatement of the reference algorithms
+(SnowingWolf/WaveformAnalysis, files under waveform_analysis/).  It is the
+*checker*: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import it.  The product (waveformanalysis_amd/) never imports it and has no
+CPU fallback.
+
+Parity status: PINNED.  tests/golden/*.npz hold inputs and outputs produced by
+running the reference's own plugins in the build container
+(tests/golden/make_golden.py); tests/test_oracle_golden.py checks every function
+below against them bit-for-bit (floats included).
+
+Third-party arithmetic: like the reference, the Savitzky-Golay / Butterworth
+filters are scipy's (`scipy.signal.savgol_filter`, `butter`, `sosfiltfilt`;
+reference call sites core/plugins/builtin/cpu/filtering.py:19,101,223,234;
+scipy is pinned only as >=1.7.0 in the reference's pyproject.toml:31, the image
+has 1.15.3).
+
+Each function cites the reference lines it follows.  "literal" functions keep
+the reference's per-record / per-hit loops (they are also what bench.py times as
+the CPU baseline); "*_uniform" helpers are vectorised equivalents for runs with
+equal-length contiguous records, used for parity at 10^6-10^8 samples and checked
+against the literal forms in tests/test_oracle_golden.py.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy.signal import butter, savgol_filter, sosfiltfilt
+
+# --- layouts (reference: core/processing/dtypes.py:80-100, hit_finder.py:33-49,
+#     basic_features.py:29-40, waveform_width_integral.py:25-39) ------------------------------
+RECORDS_DTYPE = np.dtype(
+    [
+        ("timestamp", "i8"), ("pid", "i4"), ("board", "i2"), ("channel", "i2"),
+        ("baseline", "f8"), ("baseline_upstream", "f8"), ("polarity", "U8"),
+        ("record_id", "i8"), ("dt", "i4"), ("trigger_type", "i2"), ("flags", "u4"),
+        ("wave_offset", "i8"), ("event_length", "i4"), ("time", "i8"),
+    ]
+)
+THRESHOLD_HIT_DTYPE = np.dtype(
+    [
+        ("position", "i8"), ("height", "f4"), ("integral", "f4"), ("edge_start", "i4"),
+        ("edge_end", "i4"), ("width", "f4"), ("dt", "i4"), ("rise_time", "f4"),
+        ("fall_time", "f4"), ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"),
+        ("record_id", "i8"),
+    ]
+)
+BASIC_FEATURES_DTYPE = np.dtype(
+    [
+        ("height", "f4"), ("amp", "f4"), ("area", "f4"), ("max_abs_diff", "f4"),
+        ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"), ("event_index", "i8"),
+    ]
+)
+WAVEFORM_WIDTH_INTEGRAL_DTYPE = np.dtype(
+    [
+        ("t_low", "f4"), ("t_high", "f4"), ("width", "f4"), ("t_low_samples", "f4"),
+        ("t_high_samples", "f4"), ("width_samples", "f4"), ("q_total", "f8"),
+        ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"), ("event_index", "i8"),
+    ]
+)
+
+
+# --- a3: baseline estimate --------------------------------------------------------------------
+def baseline_mean(raw: np.ndarray, start: int, end: int) -> np.ndarray:
+    """records_builder.py:243-257: mean over raw[:, start:end] as float64, NaN if empty."""
+    raw = np.asarray(raw)
+    end = min(int(end), raw.shape[1])
+    if end <= start:
+        return np.full(len(raw), np.nan, dtype=np.float64)
+    return np.mean(raw[:, start:end].astype(float), axis=1)
+
+
+# --- a4: filters ------------------------------------------------------------------------------
+def sg_window_length(n_samples: int, sg_window_size: int, sg_poly_order: int):
+    """filtering.py:181-195: effective odd window, or None when the filter is a no-op."""
+    window = min(int(sg_window_size), int(n_samples))
+    if window % 2 == 0:
+        window -= 1
+    if window <= int(sg_poly_order):
+        return None
+    return window
+
+
+def sosfiltfilt_padlen(sos: np.ndarray) -> int:
+    """filtering.py:198-203 (scipy's default pad-length heuristic)."""
+    n_sections = int(sos.shape[0])
+    zeros_at_origin = int((sos[:, 2] == 0).sum())
+    poles_at_origin = int((sos[:, 5] == 0).sum())
+    return 3 * (2 * n_sections + 1 - min(zeros_at_origin, poles_at_origin))
+
+
+def design_bw(lowcut=0.1, highcut=0.5, fs=0.5, order=4) -> np.ndarray:
+    """filtering.py:84-101."""
+    return butter(int(order), [float(lowcut), float(highcut)], btype="band", output="sos", fs=float(fs))
+
+
+def apply_filter_core(waves_f32: np.ndarray, filter_type: str = "SG", *, bw_sos=None,
+                      sg_window_size: int = 11, sg_poly_order: int = 2) -> np.ndarray:
+    """filtering.py:206-241 for a 1-D wave or a 2-D batch (axis=-1)."""
+    waves_f32 = np.asarray(waves_f32, dtype=np.float32)
+    if filter_type == "BW":
+        if waves_f32.shape[-1] <= sosfiltfilt_padlen(bw_sos):
+            return np.array(waves_f32, copy=True)
+        return np.asarray(sosfiltfilt(bw_sos, waves_f32, axis=-1), dtype=np.float32)
+    window = sg_window_length(waves_f32.shape[-1], sg_window_size, sg_poly_order)
+    if window is None:
+        return np.array(waves_f32, copy=True)
+    out = savgol_filter(waves_f32, window_length=window, polyorder=int(sg_poly_order),
+                        axis=-1, mode="interp")
+    return np.asarray(out, dtype=np.float32)
+
+
+def filter_wave_pool(records: np.ndarray, wave_pool: np.ndarray, filter_type: str = "SG", *,
+                     bw_sos=None, sg_window_size=11, sg_poly_order=2,
+                     per_record_cfg=None) -> np.ndarray:
+    """records.py:368-438 + filtering.py:377-407: float32 pool aligned to wave_pool, gaps 0.0.
+
+    per_record_cfg: optional callable(i) -> dict overriding the filter kwargs for record i
+    (the reference resolves this per hardware channel, filtering.py:339-374).
+    """
+    out = np.zeros(len(wave_pool), dtype=np.float32)
+    for i in range(len(records)):
+        length = int(records["event_length"][i])
+        if length <= 0:
+            continue
+        offset = int(records["wave_offset"][i])
+        end = offset + length
+        if offset < 0 or end > len(wave_pool):
+            raise ValueError(
+                "wave_pool_filtered found out-of-bounds wave slice "
+                f"(offset={offset}, length={length}, wave_pool_size={len(wave_pool)})"
+            )
+        kw = dict(filter_type=filter_type, bw_sos=bw_sos, sg_window_size=sg_window_size,
+                  sg_poly_order=sg_poly_order)
+        if per_record_cfg is not None:
+            kw.update(per_record_cfg(i))
+        ft = kw.pop("filter_type")
+        out[offset:end] = apply_filter_core(np.asarray(wave_pool[offset:end], dtype=np.float32), ft, **kw)
+    return out
+
+
+def filter_wave_pool_uniform(wave_pool: np.ndarray, L: int, **kw) -> np.ndarray:
+    """Vectorised filter_wave_pool for contiguous equal-length records (pool = R*L samples)."""
+    x = np.asarray(wave_pool).reshape(-1, L).astype(np.float32)
+    return apply_filter_core(x, kw.pop("filter_type", "SG"), **kw).reshape(-1)
+
+
+# --- a8: RecordsView padded batch -------------------------------------------------------------
+def waves_padded(records: np.ndarray, wave_pool: np.ndarray, dtype=np.float64):
+    """records_view.py:208-257 (`rv.waves(ids, mask=True, dtype=...)`): zero-padded matrix + mask."""
+    lengths = records["event_length"].astype(np.int64)
+    offsets = records["wave_offset"].astype(np.int64)
+    if np.any(offsets < 0):
+        raise ValueError("records contain negative wave_offset values")
+    if np.any(lengths < 0):
+        raise ValueError("records contain negative event_length values")
+    if len(records) and np.any(offsets + lengths > len(wave_pool)):
+        raise ValueError("records reference samples outside wave_pool bounds")
+    max_len = int(lengths.max()) if lengths.size else 0
+    out = np.zeros((len(records), max_len), dtype=dtype)
+    mask = np.zeros((len(records), max_len), dtype=bool)
+    for i in range(len(records)):
+        n = int(lengths[i])
+        if n == 0:
+            continue
+        out[i, :n] = wave_pool[offsets[i] : offsets[i] + n]
+        mask[i, :n] = True
+    return out, mask
+
+
+# --- a6: threshold hits -----------------------------------------------------------------------
+def positive_mask_from_polarity(records: np.ndarray) -> np.ndarray:
+    """hit_finder.py:322-325: only an explicit "positive" flips the sign."""
+    if "polarity" not in (records.dtype.names or ()):
+        return np.zeros(len(records), dtype=bool)
+    pol = np.asarray(records["polarity"]).astype("U16")
+    return pol == "positive"
+
+
+def hits_from_signal_matrix(signal, thresholds, timestamps, boards, channels, record_ids,
+                            left_extension, right_extension, dt_values, valid_mask,
+                            record_lengths) -> np.ndarray:
+    """hit_finder.py:329-413, literal (per-hit python loop)."""
+    if signal.size == 0:
+        return np.zeros(0, dtype=THRESHOLD_HIT_DTYPE)
+    mask = signal >= thresholds[:, np.newaxis]
+    if valid_mask is not None:
+        mask &= valid_mask
+    if not np.any(mask):
+        return np.zeros(0, dtype=THRESHOLD_HIT_DTYPE)
+    mask_padded = np.pad(mask, ((0, 0), (1, 1)), mode="constant", constant_values=False)
+    diff = np.diff(mask_padded.astype(np.int8), axis=1)
+    start_rows, starts = np.where(diff == 1)
+    _end_rows, ends = np.where(diff == -1)
+    n_samples = signal.shape[1]
+    hits = []
+    for hit_idx, event_idx in enumerate(start_rows.tolist()):
+        start = int(starts[hit_idx])
+        end = int(ends[hit_idx])
+        seg_start = max(0, start - left_extension)
+        seg_end = min(n_samples, end + right_extension)
+        if seg_end <= seg_start:
+            continue
+        segment = signal[event_idx, seg_start:seg_end]
+        rel_pos = int(np.argmax(segment))
+        pos = seg_start + rel_pos
+        height = float(segment[rel_pos])
+        integral = float(np.sum(np.maximum(segment, 0.0)))
+        dt_ns = int(dt_values[event_idx])
+        sampling_interval_ps = float(dt_ns) * 1e3
+        rise_time = float(max(pos - start, 0) * dt_ns)
+        fall_time = float(max((end - 1) - pos, 0) * dt_ns)
+        global_timestamp = int(timestamps[event_idx] + pos * sampling_interval_ps)
+        record_length = max(int(record_lengths[event_idx]), 0)
+        edge_start = min(max(seg_start, 0), record_length)
+        edge_end = min(max(seg_end, 0), record_length)
+        edge_end = max(edge_end, edge_start)
+        hits.append((int(pos), height, integral, edge_start, edge_end,
+                     float(edge_end - edge_start), dt_ns, rise_time, fall_time,
+                     global_timestamp, int(boards[event_idx]), int(channels[event_idx]),
+                     int(record_ids[event_idx])))
+    if hits:
+        return np.array(hits, dtype=THRESHOLD_HIT_DTYPE)
+    return np.zeros(0, dtype=THRESHOLD_HIT_DTYPE)
+
+
+def threshold_hits(records: np.ndarray, wave_pool: np.ndarray, *, threshold=10.0,
+                   thresholds=None, left_extension=2, right_extension=2) -> np.ndarray:
+    """hit_finder.py:122-255 records branch: wave_pool may be uint16 (raw) or float32 (filtered).
+
+    thresholds: optional per-record float64 array (per-channel overrides already resolved,
+    hit_finder.py:288-327).
+    """
+    if len(records) == 0:
+        return np.zeros(0, dtype=THRESHOLD_HIT_DTYPE)
+    waves, valid = waves_padded(records, wave_pool, dtype=np.float64)
+    baselines = records["baseline"].astype(np.float64)
+    thr = (np.full(len(records), float(threshold), dtype=np.float64)
+           if thresholds is None else np.asarray(thresholds, dtype=np.float64))
+    positive = positive_mask_from_polarity(records)
+    b2 = baselines[:, np.newaxis]
+    signal = np.where(positive[:, np.newaxis], waves - b2, b2 - waves)
+    return hits_from_signal_matrix(
+        signal, thr, records["timestamp"].astype(np.int64), records["board"].astype(np.int16),
+        records["channel"].astype(np.int16), records["record_id"].astype(np.int64),
+        max(0, int(left_extension)), max(0, int(right_extension)),
+        records["dt"].astype(np.int32), valid, records["event_length"].astype(np.int64))
+
+
+def threshold_hits_chunked(records, wave_pool, chunk=4096, **kw) -> np.ndarray:
+    """threshold_hits over record chunks (bounded memory).
+
+    Only valid when every chunk has the same maximum record length as the whole input
+    (the padded-width semantics of hit_finder.py:364,370 depend on it) -- true for the
+    equal-length synthetic runs this is used on.
+    """
+    thresholds = kw.pop("thresholds", None)
+    parts = []
+    for lo in range(0, len(records), chunk):
+        sub_thr = None if thresholds is None else thresholds[lo : lo + chunk]
+        parts.append(threshold_hits(records[lo : lo + chunk], wave_pool, thresholds=sub_thr, **kw))
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=THRESHOLD_HIT_DTYPE)
+
+
+# --- a9: basic features -----------------------------------------------------------------------
+def _normalized_signal_f32(rec, wave, baseline):
+    """records_view.py:87-100: f32(w) - f32(b), negated iff polarity == "positive"."""
+    signal = wave.astype(np.float32, copy=False) - np.asarray(baseline, dtype=np.float32)
+    if str(rec["polarity"]) == "positive":
+        signal = -signal
+    return signal
+
+
+def basic_features(records: np.ndarray, wave_pool: np.ndarray, *, height_range=(40, 90),
+                   area_range=(0, None), fixed_baseline=None) -> np.ndarray:
+    """basic_features.py:108-195 records branch, literal per-record loop.
+
+    fixed_baseline: optional per-record array, NaN = "use records.baseline"
+    (the per-channel override of basic_features.py:133-146 already resolved).
+    """
+    start_p, end_p = height_range
+    start_c, end_c = area_range
+    out = np.zeros(len(records), dtype=BASIC_FEATURES_DTYPE)
+    has_pol = "polarity" in (records.dtype.names or ())
+    for idx, rec in enumerate(records):
+        baseline = float(rec["baseline"])
+        if fixed_baseline is not None and not np.isnan(fixed_baseline[idx]):
+            baseline = float(fixed_baseline[idx])
+        off, n = int(rec["wave_offset"]), int(rec["event_length"])
+        wave = wave_pool[off : off + n]
+        pol = str(rec["polarity"]) if has_pol else None
+        use_norm = pol in ("positive", "negative")
+        signal = -_normalized_signal_f32(rec, wave, baseline) if use_norm else None
+        wave_p, wave_c = wave[start_p:end_p], wave[start_c:end_c]
+        signal_p = signal[start_p:end_p] if signal is not None else None
+        signal_c = signal[start_c:end_c] if signal is not None else None
+        eff = pol if use_norm else "negative"
+        if use_norm and signal_p.size > 0:
+            s_min, s_max = float(np.min(signal_p)), float(np.max(signal_p))
+            out["height"][idx] = s_max
+            out["amp"][idx] = s_max - s_min
+        elif wave_p.size > 0:
+            w_min, w_max = float(np.min(wave_p)), float(np.max(wave_p))
+            out["height"][idx] = (w_max - baseline) if eff == "positive" else (baseline - w_min)
+            out["amp"][idx] = w_max - w_min
+        if use_norm and signal_c.size > 0:
+            out["area"][idx] = float(np.sum(signal_c.astype(np.float64, copy=False)))
+        elif wave_c.size > 0:
+            wave_c64 = wave_c.astype(np.float64)
+            b64 = np.asarray(baseline, dtype=np.float64)
+            out["area"][idx] = float(np.sum(wave_c64 - b64)) if eff == "positive" else float(np.sum(b64 - wave_c64))
+        if wave.size > 1:
+            out["max_abs_diff"][idx] = float(np.max(np.abs(np.diff(wave.astype(np.float64, copy=False)))))
+        out["timestamp"][idx] = int(rec["timestamp"])
+        out["board"][idx] = int(rec["board"])
+        out["channel"][idx] = int(rec["channel"])
+        out["event_index"][idx] = idx
+    return out
+
+
+# --- a10: integral-quantile width -------------------------------------------------------------
+def width_integral(records: np.ndarray, wave_pool: np.ndarray, *, q_low=0.10, q_high=0.90,
+                   dt=None, sampling_rate=0.5) -> np.ndarray:
+    """waveform_width_integral.py:83-231 records branch, literal per-record loop."""
+    if dt is None:
+        dt = 1.0 / float(sampling_rate)
+    has_pol = "polarity" in (records.dtype.names or ())
+    rows = []
+    for idx, rec in enumerate(records):
+        off, n = int(rec["wave_offset"]), int(rec["event_length"])
+        wave = wave_pool[off : off + n]
+        baseline = float(rec["baseline"])
+        pol = str(rec["polarity"]) if has_pol else "unknown"
+        if pol in ("positive", "negative"):
+            signal = -_normalized_signal_f32(rec, wave, rec["baseline"]).astype(np.float64, copy=False)
+        else:
+            raw_signal = wave.astype(np.float64, copy=False) - baseline
+            signal = raw_signal if pol == "positive" else -raw_signal
+        x = np.maximum(signal, 0.0)
+        q_total = float(np.sum(x))
+        if q_total <= 0 or not np.isfinite(q_total):
+            lo = hi = w = 0.0
+        else:
+            cumsum = np.cumsum(x)
+            lo_i = int(np.searchsorted(cumsum, q_low * q_total, side="left"))
+            hi_i = int(np.searchsorted(cumsum, q_high * q_total, side="left"))
+            lo, hi, w = float(lo_i), float(hi_i), float(max(hi_i - lo_i, 0))
+        rows.append((float(lo * dt), float(hi * dt), float(w * dt), lo, hi, w, q_total,
+                     int(rec["timestamp"]), int(rec["board"]), int(rec["channel"]), idx))
+    if rows:
+        return np.array(rows, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)
+    return np.zeros(0, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)

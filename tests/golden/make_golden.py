@@ -1,0 +1,239 @@
+"""Generate tests/golden/*.npz by running the REFERENCE plugins (build container only).
+
+Usage (from any scratch cwd; the reference tree is never written to):
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 /root/repo/tests/golden/make_golden.py
+
+The reference (/root/reference) is imported here and only here.  Every fixture stores the
+inputs (records, wave_pool, options) and the outputs of the reference's own plugin classes:
+    WavePoolFilteredPlugin      core/plugins/builtin/cpu/records.py:334-438
+    ThresholdHitPlugin          core/plugins/builtin/cpu/hit_finder.py:82-413
+    BasicFeaturesPlugin         core/plugins/builtin/cpu/basic_features.py:43-278
+    WaveformWidthIntegralPlugin core/plugins/builtin/cpu/waveform_width_integral.py:42-235
+driven through a minimal context object (the same subset of Context the reference's
+tests/utils.py:FakeContext implements).  Fixtures are data only.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+os.chdir(tempfile.mkdtemp(prefix="wfa_golden_"))
+sys.dont_write_bytecode = True
+
+from waveform_analysis.core.plugins.builtin.cpu.basic_features import BasicFeaturesPlugin  # noqa: E402
+from waveform_analysis.core.plugins.builtin.cpu.hit_finder import ThresholdHitPlugin  # noqa: E402
+from waveform_analysis.core.plugins.builtin.cpu.records import WavePoolFilteredPlugin  # noqa: E402
+from waveform_analysis.core.plugins.builtin.cpu.waveform_width_integral import (  # noqa: E402
+    WaveformWidthIntegralPlugin,
+)
+from waveform_analysis.core.processing.dtypes import RECORDS_DTYPE  # noqa: E402
+
+from waveformanalysis_amd import synth  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+class Ctx:
+    """Minimal context: config lookup order plugin-nested > namespaced > global > default."""
+
+    def __init__(self, config, data):
+        self.config = dict(config)
+        self._data = dict(data)
+        self._results = {}
+        self._plugins = {}
+
+    def get_config(self, plugin, name):
+        prov = plugin.provides
+        if isinstance(self.config.get(prov), dict) and name in self.config[prov]:
+            return self.config[prov][name]
+        if f"{prov}.{name}" in self.config:
+            return self.config[f"{prov}.{name}"]
+        if name in self.config:
+            return self.config[name]
+        if name in plugin.options:
+            return plugin.options[name].default
+        return None
+
+    def get_data(self, run_id, name):
+        if (run_id, name) in self._results:
+            return self._results[(run_id, name)]
+        return self._data.get(name)
+
+    def _set_data(self, run_id, name, value):
+        self._results[(run_id, name)] = value
+
+
+def run_case(name, records, pool, *, filter_cfg=None, hit_cfg=None, bf_cfg=None, wi_cfg=None,
+             want=("filtered", "hits_raw", "hits_filt", "bf_raw", "bf_filt", "wi_raw", "wi_filt")):
+    filter_cfg = dict(filter_cfg or {})
+    hit_cfg = dict(hit_cfg or {})
+    bf_cfg = dict(bf_cfg or {})
+    wi_cfg = dict(wi_cfg or {})
+    out = {"records": records, "wave_pool": pool}
+    opts = {"filter": filter_cfg, "hit": hit_cfg, "bf": bf_cfg, "wi": wi_cfg}
+
+    fctx = Ctx({"max_workers": 1, **filter_cfg}, {"records": records, "wave_pool": pool})
+    filtered = WavePoolFilteredPlugin().compute(fctx, "run")
+    assert filtered.dtype == np.float32
+    if "filtered" in want:
+        out["wave_pool_filtered"] = filtered
+    data = {"records": records, "wave_pool": pool, "wave_pool_filtered": filtered}
+
+    def run(plugin, cfg, use_filtered):
+        ctx = Ctx({"wave_source": "records", "use_filtered": use_filtered, **cfg}, data)
+        return plugin.compute(ctx, "run")
+
+    if "hits_raw" in want:
+        out["hits_raw"] = run(ThresholdHitPlugin(), hit_cfg, False)
+    if "hits_filt" in want:
+        out["hits_filt"] = run(ThresholdHitPlugin(), hit_cfg, True)
+    if "bf_raw" in want:
+        out["bf_raw"] = run(BasicFeaturesPlugin(), bf_cfg, False)
+    if "bf_filt" in want:
+        out["bf_filt"] = run(BasicFeaturesPlugin(), bf_cfg, True)
+    if "wi_raw" in want:
+        out["wi_raw"] = run(WaveformWidthIntegralPlugin(), wi_cfg, False)
+    if "wi_filt" in want:
+        out["wi_filt"] = run(WaveformWidthIntegralPlugin(), wi_cfg, True)
+    out["options_json"] = np.frombuffer(json.dumps(opts, default=str).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    sizes = {k: (len(v) if hasattr(v, "__len__") else v) for k, v in out.items()}
+    print(f"{name}: {sizes} -> {os.path.getsize(path)} B")
+
+
+def flip_positive(records, pool):
+    """Mirror pulses around the record baseline so they are positive-going."""
+    rec = records.copy()
+    rec["polarity"] = "positive"
+    L = int(rec["event_length"][0])
+    w = pool.reshape(-1, L).astype(np.int64)
+    ped = np.rint(rec["baseline"]).astype(np.int64)[:, None]
+    flipped = np.clip(2 * ped - w, 0, 16383).astype(np.uint16)
+    rec["baseline"] = flipped[:, :40].sum(axis=1, dtype=np.int64) / 40.0
+    return rec, flipped.reshape(-1)
+
+
+def ragged_case(seed=7):
+    """Mixed-length records with gaps, short records (incl. 0/1/3/5/7/8/12/16) and edge pulses."""
+    rng = np.random.default_rng(seed)
+    lengths = [800, 8, 16, 0, 7, 1500, 3, 12, 1, 5, 64, 65, 63, 200, 11, 10, 9, 128, 13, 800]
+    n = len(lengths)
+    records = np.zeros(n, dtype=RECORDS_DTYPE)
+    chunks, cursor = [], 0
+    for i, L in enumerate(lengths):
+        gap = int(rng.integers(0, 5))
+        chunks.append(np.full(gap, 12345, dtype=np.uint16))  # garbage between records
+        cursor += gap
+        ped = int(rng.integers(90, 8200))
+        w = np.rint(ped + rng.normal(0, 3, L)).astype(np.int64)
+        if L >= 8:
+            s = int(rng.integers(0, L - 3))
+            e = min(L, s + int(rng.integers(2, max(3, L // 4))))
+            w[s:e] -= int(rng.integers(15, min(ped, 2000)))
+        if i in (1, 2, 12):  # pulse touching the record end -> padded-width semantics
+            w[-2:] -= 20
+        records["wave_offset"][i] = cursor
+        records["event_length"][i] = L
+        nb = min(40, L)
+        records["baseline"][i] = float(np.mean(w[:nb].astype(float))) if nb else np.nan
+        chunks.append(np.clip(w, 0, 65535).astype(np.uint16))
+        cursor += L
+    chunks.append(np.full(3, 54321, dtype=np.uint16))
+    pool = np.concatenate(chunks)
+    records["timestamp"] = np.cumsum(rng.integers(1, 10**7, n)).astype(np.int64) + 10**12
+    records["board"] = rng.integers(0, 3, n)
+    records["channel"] = rng.integers(0, 4, n)
+    records["record_id"] = np.arange(n)
+    records["dt"] = rng.choice([1, 2, 4], n)
+    records["polarity"] = "unknown"
+    records["baseline_upstream"] = np.nan
+    return records, pool
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+
+    rec, pool = synth.make_run(64, "v1725", cfg=0)
+    run_case("v1725_default", rec, pool)
+
+    rec, pool = synth.make_run(24, "vx2730", cfg=1)
+    run_case("vx2730_default", rec, pool)
+
+    rec, pool = synth.make_run(32, "v1725", cfg=2)
+    rneg = rec.copy()
+    rneg["polarity"] = "negative"
+    run_case("v1725_negative", rneg, pool)
+    rpos, ppos = flip_positive(rec, pool)
+    run_case("v1725_positive", rpos, ppos)
+
+    for W, P in [(5, 2), (7, 3), (9, 4), (31, 3), (21, 4), (12, 2)]:
+        rec, pool = synth.make_run(16, "v1725", cfg=10 + W)
+        run_case(f"v1725_sg{W}_{P}", rec, pool,
+                 filter_cfg={"sg_window_size": W, "sg_poly_order": P},
+                 want=("filtered", "hits_filt", "bf_filt", "wi_filt"))
+
+    rec, pool = synth.make_run(16, "v1725", cfg=40)
+    run_case("v1725_bw", rec, pool, filter_cfg={"filter_type": "BW", "lowcut": 0.01, "highcut": 0.2, "fs": 0.5},
+             want=("filtered", "hits_filt", "bf_filt", "wi_filt"))
+
+    rec, pool = ragged_case()
+    run_case("ragged_mixed", rec, pool)
+    run_case("ragged_mixed_ext", rec, pool, hit_cfg={"left_extension": 5, "right_extension": 7,
+                                                     "threshold": 6.5},
+             bf_cfg={"height_range": (0, 6), "area_range": (2, 40)},
+             wi_cfg={"q_low": 0.25, "q_high": 0.6, "dt": 4.0})
+
+    # survey section 7 "padded-matrix semantics" known answer (lengths 8 and 16, baseline 100)
+    records = np.zeros(2, dtype=RECORDS_DTYPE)
+    records["baseline"] = 100.0
+    records["timestamp"] = [1_000_000, 2_000_000]
+    records["record_id"] = [0, 1]
+    records["dt"] = 2
+    records["event_length"] = [8, 16]
+    records["wave_offset"] = [0, 8]
+    records["polarity"] = "unknown"
+    pool = np.array([100] * 6 + [80, 80] + [100] * 16, dtype=np.uint16)
+    run_case("kat_padded_width", records, pool, want=("filtered", "hits_raw", "hits_filt", "bf_raw", "wi_raw"))
+
+    # reference KAT: tests/plugins/test_threshold_hit_plugin.py:33-43 records view
+    records = np.zeros(1, dtype=RECORDS_DTYPE)
+    records["baseline"] = 100.0
+    records["timestamp"] = 123_456
+    records["board"] = 5
+    records["channel"] = 2
+    records["dt"] = 2
+    records["event_length"] = 8
+    records["polarity"] = "unknown"
+    pool = np.array([100, 100, 80, 80, 80, 80, 100, 100], dtype=np.uint16)
+    run_case("kat_records_view", records, pool, hit_cfg={"left_extension": 0, "right_extension": 0})
+
+    # per-channel thresholds + fixed baseline overrides
+    rec, pool = synth.make_run(48, "v1725", cfg=3)
+    run_case("v1725_channel_cfg", rec, pool,
+             hit_cfg={"threshold": 25.0, "channel_config": {"0:3": {"threshold": 8.0},
+                                                            "0:7": {"threshold": 300.0}}},
+             bf_cfg={"channel_config": {"0:3": {"fixed_baseline": 8000.0},
+                                        "defaults": {"fixed_baseline": None}}})
+
+    # large timestamps (float64 rounding of the hit timestamp), saturated + near-zero samples
+    rec, pool = synth.make_run(16, "v1725", cfg=4)
+    rec["timestamp"] += np.int64(2**60)
+    pool = pool.copy()
+    pool[100:130] = 0
+    pool[900:905] = 16383
+    pool[800 * 5 : 800 * 6] = np.random.default_rng(5).integers(0, 4, 800)
+    rec["baseline"][5] = pool[800 * 5 : 800 * 5 + 40].mean()
+    run_case("v1725_extremes", rec, pool, hit_cfg={"threshold": 1.5})
+
+
+if __name__ == "__main__":
+    main()
