@@ -1,0 +1,167 @@
+/*
+ * wfa_hip.h -- C ABI of libwfa_hip.so, the MI355X (gfx950) backend for the per-record
+ * waveform hot path of SnowingWolf/WaveformAnalysis.
+ *
+ * The reference is pure Python; there is no FFI to replace.  Each entry point below names
+ * the reference function whose inner loop it replaces (paths relative to
+ * waveform_analysis/).  The Python plugins in waveformanalysis_amd/plugins/ bind these
+ * through ctypes (waveformanalysis_amd/_lib.py); INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C, caller-allocated host buffers, no callbacks;
+ *   - every function returns 0 on success or a negative WFA_E_* code;
+ *     wfa_last_error() returns the message of the calling thread's last failure;
+ *   - one wfa_ctx per (GPU, host thread); a ctx owns one HIP stream and its device
+ *     buffers; calls on one ctx are serialised by the caller;
+ *   - the pool and the records SoA stay resident in HBM between calls, so
+ *     filter -> hits -> features read them without another host transfer.
+ */
+#ifndef WFA_HIP_H
+#define WFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFA_ABI_VERSION 1
+
+#define WFA_OK 0
+#define WFA_E_INVALID (-1)   /* bad argument / malformed records (maps to ValueError) */
+#define WFA_E_HIP (-2)       /* HIP runtime failure */
+#define WFA_E_STATE (-3)     /* call order: something required was not uploaded / planned */
+#define WFA_E_NOMEM (-4)
+#define WFA_E_RCCL (-5)
+#define WFA_E_LIMIT (-6)     /* record longer than WFA_MAX_RECORD_SAMPLES etc. */
+
+#define WFA_MAX_RECORD_SAMPLES 32760
+#define WFA_MAX_SG_WINDOW 63
+
+/* wave source of a consumer (reference: cpu/_wave_source.py:119-165, records branch) */
+#define WFA_SRC_RAW 0        /* wave_pool (uint16)                                        */
+#define WFA_SRC_F32 1        /* wave_pool_filtered (float32) resident on the device       */
+#define WFA_SRC_SG_FUSED 2   /* Savitzky-Golay of wave_pool evaluated on the fly, never   */
+                             /* materialised (the fused baseline+filter+hitfind pass)     */
+
+/* polarity code per record (reference: records["polarity"], dtypes.py:87) */
+#define WFA_POL_UNKNOWN 0
+#define WFA_POL_NEGATIVE 1
+#define WFA_POL_POSITIVE 2
+
+typedef struct wfa_ctx wfa_ctx;
+
+int wfa_abi_version(void);
+int wfa_device_count(int* count);
+int wfa_last_error(char* buf, size_t buf_len);
+
+int wfa_ctx_create(int device_id, wfa_ctx** out);
+void wfa_ctx_destroy(wfa_ctx* ctx);
+int wfa_sync(wfa_ctx* ctx);
+
+/* ---- resident inputs -------------------------------------------------------------------- */
+
+/* wave_pool: flat uint16 samples (reference: processing/records_builder.py:197,299;
+ * plugins/builtin/cpu/records.py:321-331). */
+int wfa_upload_pool_u16(wfa_ctx* ctx, const uint16_t* pool, int64_t n_samples);
+
+/* wave_pool_filtered produced elsewhere (reference: records.py:334-438 output). */
+int wfa_upload_pool_f32(wfa_ctx* ctx, const float* pool, int64_t n_samples);
+
+/* Records index table as structure-of-arrays (reference row layout: processing/dtypes.py:80-100;
+ * the per-channel option lookups of hit_finder.py:288-327 are resolved by the caller into
+ * `threshold`).  Validates 0 <= offset, 0 <= length <= WFA_MAX_RECORD_SAMPLES,
+ * offset+length <= pool size (reference: data/records_view.py:47-56). */
+int wfa_upload_records_soa(wfa_ctx* ctx, int64_t n_records,
+                           const int64_t* wave_offset, const int32_t* event_length,
+                           const double* baseline, const int8_t* polarity_code,
+                           const double* threshold, const int64_t* timestamp,
+                           const int32_t* dt_ns, const int16_t* board, const int16_t* channel,
+                           const int64_t* record_id);
+
+/* Savitzky-Golay plan (reference: cpu/filtering.py:181-195,226-240 + scipy.signal.savgol_filter
+ * mode="interp").  Tables are built on the host (waveformanalysis_amd/sg_plan.py):
+ *   n_tables = (window+1)/2; table t serves effective window w = 2t+1 (short records,
+ *   filtering.py:187-193); a table with w <= polyorder is unused (filter is a copy).
+ *   tab: n_tables * (window + 2*(window/2)*window) doubles:
+ *        [ fw[window] | E_left[window/2][window] | E_right[window/2][window] ] per table
+ *        fw = correlation weights (savgol_coeffs reversed), E = polynomial edge projection.
+ *   symmetric[t]: 1 if ndimage.correlate1d takes its symmetric branch for fw.
+ *   Integer plan for the full window (exact rational arithmetic):
+ *        itab: [ n[window] | NL[window/2][window] | NR[window/2][window] ] int32,
+ *        y = n.x / den (interior), edges N.x / den_edge; guard_* = |numerator| below which
+ *        the kernel evaluates the float64 chain instead.  int_ok = 0 disables it. */
+int wfa_set_sg_plan(wfa_ctx* ctx, int window, int polyorder, const double* tab,
+                    const uint8_t* symmetric, int int_ok, const int32_t* itab, int32_t den,
+                    int32_t den_edge, int64_t guard, int64_t guard_edge);
+
+/* ---- kernels ---------------------------------------------------------------------------- */
+
+/* K1 baseline estimate: mean of samples [start, end) of every record as float64, NaN when
+ * the window is empty (reference: records_builder.py:243-257, waveforms.py:714-733).
+ * Writes the device-resident baseline column when update_records != 0; out may be NULL. */
+int wfa_baseline_mean(wfa_ctx* ctx, int32_t start, int32_t end, int update_records, double* out);
+
+/* K2 wave_pool_filtered: float32 pool aligned to wave_pool, gaps 0.0
+ * (reference: records.py:368-438, filtering.py:377-407).  The result stays resident as the
+ * WFA_SRC_F32 pool; out may be NULL. */
+int wfa_savgol(wfa_ctx* ctx, float* out);
+
+/* K4 threshold hits (reference: hit_finder.py:231-255,329-413).  Two-phase so the caller can
+ * allocate the structured array: _count runs the pass and returns the number of rows,
+ * _fill copies them (THRESHOLD_HIT_DTYPE, 60-byte packed rows, order = record index, start).
+ * max_len = padded matrix width of the reference call (max event_length over the whole
+ * records array, hit_finder.py:364,370); pass 0 to use the maximum of the uploaded records. */
+int wfa_threshold_hits_count(wfa_ctx* ctx, int source, int32_t left_extension,
+                             int32_t right_extension, int32_t max_len, int64_t* n_hits);
+int wfa_threshold_hits_fill(wfa_ctx* ctx, void* out_rows, int64_t n_hits);
+
+/* K7 fused pass: baseline estimate over [bl_start, bl_end) (skipped if bl_end <= bl_start:
+ * the uploaded baseline is used) + Savitzky-Golay + threshold hits in one read of the pool. */
+int wfa_fused_baseline_filter_hits(wfa_ctx* ctx, int32_t bl_start, int32_t bl_end,
+                                   int32_t left_extension, int32_t right_extension,
+                                   int32_t max_len, int64_t* n_hits);
+
+/* K5 basic features (reference: basic_features.py:108-195).  Ranges are python slice bounds;
+ * *_has_end = 0 means "None".  fixed_baseline: per-record override, NaN = none, may be NULL.
+ * out: BASIC_FEATURES_DTYPE rows (36 B). */
+int wfa_basic_features(wfa_ctx* ctx, int source, int64_t height_start, int64_t height_end,
+                       int height_has_end, int64_t area_start, int64_t area_end, int area_has_end,
+                       const double* fixed_baseline, void* out_rows);
+
+/* K6 integral-quantile width (reference: waveform_width_integral.py:166-227).
+ * out: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B). */
+int wfa_width_integral(wfa_ctx* ctx, int source, double q_low, double q_high, double dt,
+                       void* out_rows);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+/* When enabled every kernel launch is bracketed by HIP events on the ctx stream. */
+int wfa_profile_enable(wfa_ctx* ctx, int on);
+int wfa_profile_reset(wfa_ctx* ctx);
+/* idx-th profiled kernel: name (<= name_len), summed milliseconds, launches. Returns
+ * WFA_E_INVALID past the end. */
+int wfa_profile_get(wfa_ctx* ctx, int idx, char* name, size_t name_len, double* total_ms,
+                    int64_t* launches);
+
+/* ---- multi-GPU gather for event grouping (RCCL over xGMI) -------------------------------- */
+
+/* 128-byte unique id created on rank 0 and broadcast by the launcher. */
+int wfa_rccl_unique_id(void* id128);
+int wfa_rccl_init(wfa_ctx* ctx, int rank, int n_ranks, const void* id128);
+/* Step 1: every rank learns counts[n_ranks] (one int64 all-gather). */
+int wfa_rccl_allgather_counts(wfa_ctx* ctx, int64_t n_rows, int64_t* counts);
+/* Step 2: all ranks send n_rows rows of row_bytes each to `root` (grouped send/recv); the
+ * root receives them concatenated in rank order into out (host buffer of sum(counts) rows,
+ * ignored elsewhere).  rows == NULL sends the device-resident rows of the last hit pass
+ * (row_bytes must be 60) without a host round trip.  counts = result of step 1. */
+int wfa_rccl_gather_rows(wfa_ctx* ctx, const void* rows, int64_t n_rows, int32_t row_bytes,
+                         int root, const int64_t* counts, void* out);
+int wfa_rccl_destroy(wfa_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFA_HIP_H */

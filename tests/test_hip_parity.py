@@ -1,0 +1,180 @@
+"""HIP kernels through the C ABI vs the golden fixtures (reference outputs) and the oracle.
+
+Integer fields (positions, edges, timestamps, ids) must be bit-exact.  Float fields are compared
+bit-exact where the kernel reproduces the reference's evaluation order, else within
+FLOAT_RTOL = 1e-6 (north_star tolerance for areas / widths), stated per test.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import wfa_oracle as O
+from tests import golden_util as G
+from waveformanalysis_amd import _lib, synth
+from waveformanalysis_amd.device import DeviceSession
+from waveformanalysis_amd.plugin_api import SimpleContext
+from waveformanalysis_amd.plugins import (
+    HipBasicFeaturesPlugin,
+    HipThresholdHitPlugin,
+    HipWaveformWidthIntegralPlugin,
+    HipWavePoolFilteredPlugin,
+)
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_RTOL = 1e-6
+SG_CASES = [n for n in G.case_names() if n != "v1725_bw"]
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = DeviceSession(0)
+    yield s
+    s.close()
+
+
+def _sg(case):
+    fp = G.filter_params(case)
+    return fp["sg_window_size"], fp["sg_poly_order"]
+
+
+@pytest.mark.parametrize("name", SG_CASES)
+def test_savgol_materialised_bit_exact(sess, name):
+    case = G.load_case(name)
+    sess.upload_pool(case["wave_pool"])
+    sess.upload_records(case["records"])
+    sess.set_sg_plan(*_sg(case))
+    got = sess.savgol()
+    np.testing.assert_array_equal(got, case["wave_pool_filtered"])
+
+
+@pytest.mark.parametrize("name", G.case_names())
+def test_hits_raw_and_prefiltered(sess, name):
+    case = G.load_case(name)
+    hp = G.hit_params(case)
+    if "hits_raw" in case:
+        sess.upload_pool(case["wave_pool"])
+        sess.upload_records(case["records"], hp["thresholds"])
+        got = sess.threshold_hits(_lib.SRC_RAW, hp["left_extension"], hp["right_extension"])
+        G.assert_struct_equal(got, case["hits_raw"], float_rtol=FLOAT_RTOL, what=f"{name} hits_raw")
+    if "hits_filt" in case:
+        sess.upload_pool(case["wave_pool"])
+        sess.upload_filtered_pool(case["wave_pool_filtered"])
+        sess.upload_records(case["records"], hp["thresholds"])
+        got = sess.threshold_hits(_lib.SRC_F32, hp["left_extension"], hp["right_extension"])
+        G.assert_struct_equal(got, case["hits_filt"], float_rtol=FLOAT_RTOL, what=f"{name} hits_filt")
+
+
+@pytest.mark.parametrize("name", SG_CASES)
+def test_hits_fused_filter(sess, name):
+    case = G.load_case(name)
+    if "hits_filt" not in case:
+        pytest.skip("no filtered hits in fixture")
+    hp = G.hit_params(case)
+    sess.upload_pool(case["wave_pool"])
+    sess.upload_records(case["records"], hp["thresholds"])
+    sess.set_sg_plan(*_sg(case))
+    got = sess.threshold_hits(_lib.SRC_SG_FUSED, hp["left_extension"], hp["right_extension"])
+    G.assert_struct_equal(got, case["hits_filt"], float_rtol=FLOAT_RTOL, what=f"{name} fused")
+
+
+def test_fused_baseline_filter_hits(sess):
+    case = G.load_case("v1725_default")
+    rec = case["records"].copy()
+    want_bl = rec["baseline"].copy()
+    rec["baseline"] = -1.0  # must be recomputed by the kernel
+    sess.upload_pool(case["wave_pool"])
+    sess.upload_records(rec, 10.0)
+    sess.set_sg_plan(11, 2)
+    got = sess.fused_baseline_filter_hits((0, 40))
+    G.assert_struct_equal(got, case["hits_filt"], float_rtol=FLOAT_RTOL, what="fused baseline")
+    np.testing.assert_array_equal(sess.baseline_mean(0, 40), want_bl)
+    assert np.all(np.isnan(sess.baseline_mean(7, 7)))
+
+
+@pytest.mark.parametrize("name", G.case_names())
+def test_basic_features(sess, name):
+    case = G.load_case(name)
+    bp = G.bf_params(case)
+    fixed = None if np.all(np.isnan(bp["fixed_baseline"])) else bp["fixed_baseline"]
+    for key, pool, src in (("bf_raw", "wave_pool", _lib.SRC_RAW), ("bf_filt", "wave_pool_filtered", _lib.SRC_F32)):
+        if key not in case:
+            continue
+        sess.upload_pool(case["wave_pool"])
+        if src == _lib.SRC_F32:
+            sess.upload_filtered_pool(case[pool])
+        sess.upload_records(case["records"])
+        got = sess.basic_features(src, bp["height_range"], bp["area_range"], fixed)
+        G.assert_struct_equal(got, case[key], float_rtol=FLOAT_RTOL, float_atol=1e-4, what=f"{name} {key}")
+
+
+@pytest.mark.parametrize("name", G.case_names())
+def test_width_integral(sess, name):
+    case = G.load_case(name)
+    wp = G.wi_params(case)
+    dt = wp["dt"] if wp["dt"] is not None else 1.0 / wp["sampling_rate"]
+    for key, pool, src in (("wi_raw", "wave_pool", _lib.SRC_RAW), ("wi_filt", "wave_pool_filtered", _lib.SRC_F32)):
+        if key not in case:
+            continue
+        sess.upload_pool(case["wave_pool"])
+        if src == _lib.SRC_F32:
+            sess.upload_filtered_pool(case[pool])
+        sess.upload_records(case["records"])
+        got = sess.width_integral(src, wp["q_low"], wp["q_high"], float(dt))
+        G.assert_struct_equal(got, case[key], float_rtol=FLOAT_RTOL, what=f"{name} {key}")
+
+
+def test_against_oracle_medium(sess):
+    """2*10^6 samples, uniform records: every stage against the oracle on the same seeded input."""
+    rec, pool = synth.make_run(2500, "v1725", cfg=21)
+    sess.upload_pool(pool)
+    sess.upload_records(rec, 10.0)
+    sess.set_sg_plan(11, 2)
+    filt = sess.savgol()
+    want_filt = O.filter_wave_pool_uniform(pool, 800)
+    np.testing.assert_array_equal(filt, want_filt)
+    G.assert_struct_equal(sess.threshold_hits(_lib.SRC_RAW), O.threshold_hits_chunked(rec, pool),
+                          float_rtol=FLOAT_RTOL, what="raw hits")
+    want = O.threshold_hits_chunked(rec, want_filt)
+    G.assert_struct_equal(sess.threshold_hits(_lib.SRC_F32), want, float_rtol=FLOAT_RTOL, what="f32 hits")
+    G.assert_struct_equal(sess.threshold_hits(_lib.SRC_SG_FUSED), want, float_rtol=FLOAT_RTOL, what="fused hits")
+    G.assert_struct_equal(sess.basic_features(_lib.SRC_RAW), O.basic_features(rec, pool),
+                          float_rtol=FLOAT_RTOL, float_atol=1e-4, what="bf")
+    G.assert_struct_equal(sess.width_integral(_lib.SRC_RAW, dt=2.0), O.width_integral(rec, pool),
+                          float_rtol=FLOAT_RTOL, what="wi")
+
+
+def test_plugins_drop_in_chain():
+    """The plugin classes behind a context, chained like the reference profile."""
+    case = G.load_case("v1725_channel_cfg")
+    opt = case["options"]
+    ctx = SimpleContext(
+        {"hit_threshold": {**opt["hit"], "use_filtered": True}, "basic_features": opt["bf"]},
+        {"records": case["records"], "wave_pool": case["wave_pool"]},
+        plugins=[HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
+                 HipWaveformWidthIntegralPlugin()],
+    )
+    np.testing.assert_array_equal(ctx.get_data("run", "wave_pool_filtered"), case["wave_pool_filtered"])
+    G.assert_struct_equal(ctx.get_data("run", "hit_threshold"), case["hits_filt"], float_rtol=FLOAT_RTOL)
+    G.assert_struct_equal(ctx.get_data("run", "basic_features"), case["bf_raw"], float_rtol=FLOAT_RTOL, float_atol=1e-4)
+    G.assert_struct_equal(ctx.get_data("run", "waveform_width_integral"), case["wi_raw"], float_rtol=FLOAT_RTOL)
+    # fused variant gives the same hits without materialising the filtered pool
+    ctx2 = SimpleContext({"hit_threshold": {**opt["hit"], "use_filtered": True, "fuse_filter": True}},
+                         {"records": case["records"], "wave_pool": case["wave_pool"]},
+                         plugins=[HipWavePoolFilteredPlugin(), HipThresholdHitPlugin()])
+    G.assert_struct_equal(ctx2.get_data("run", "hit_threshold"), case["hits_filt"], float_rtol=FLOAT_RTOL)
+
+
+def test_error_behaviour(sess):
+    case = G.load_case("kat_records_view")
+    sess.upload_pool(case["wave_pool"])
+    bad = case["records"].copy()
+    bad["wave_offset"] = 4
+    with pytest.raises(ValueError, match="outside wave_pool bounds"):
+        sess.upload_records(bad)
+    bad["wave_offset"] = -1
+    with pytest.raises(ValueError, match="negative wave_offset"):
+        sess.upload_records(bad)
+    with pytest.raises(ValueError, match="q_low/q_high"):
+        sess.upload_records(case["records"])
+        sess.width_integral(_lib.SRC_RAW, 0.9, 0.1, 1.0)

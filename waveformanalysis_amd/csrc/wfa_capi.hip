@@ -1,0 +1,525 @@
+// C ABI of libwfa_hip.so (see include/wfa_hip.h): context, resident buffers, kernel calls.
+
+#include <cmath>
+#include <new>
+
+#include "wfa_common.hpp"
+#include "wfa_kernels.hpp"
+
+namespace wfa {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int DevBuf::ensure(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (bytes <= cap) return WFA_OK;
+    if (ptr) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    // 256 B of slack so 16-byte vector loads at the tail stay inside the allocation
+    hipError_t e = hipMalloc(&ptr, bytes + 256);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        return fail(WFA_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    cap = bytes;
+    return WFA_OK;
+}
+
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+static int use_device(wfa_ctx* c) {
+    if (!c) return fail(WFA_E_INVALID, "null context");
+    WFA_HIP_CHECK(hipSetDevice(c->device));
+    return WFA_OK;
+}
+
+static int h2d(wfa_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = b.ensure(bytes);
+    if (rc) return rc;
+    if (bytes) WFA_HIP_CHECK(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return WFA_OK;
+}
+
+static PoolView pool_view(wfa_ctx* c) {
+    PoolView p;
+    p.u16 = c->have_u16 ? c->pool_u16.as<uint16_t>() : nullptr;
+    p.f32 = c->have_f32 ? c->pool_f32.as<float>() : nullptr;
+    p.n = c->pool_n;
+    return p;
+}
+
+static RecView rec_view(wfa_ctx* c) {
+    RecView r;
+    r.R = c->R;
+    r.off = c->off.as<int64_t>();
+    r.len = c->len.as<int32_t>();
+    r.baseline = c->baseline.as<double>();
+    r.baseline_rw = c->baseline.as<double>();
+    r.pol = c->pol.as<int8_t>();
+    r.thr = c->thr.as<double>();
+    r.ts = c->ts.as<int64_t>();
+    r.dt = c->dt.as<int32_t>();
+    r.board = c->board.as<int16_t>();
+    r.chan = c->chan.as<int16_t>();
+    r.rid = c->rid.as<int64_t>();
+    return r;
+}
+
+static SgParams sg_params(wfa_ctx* c) {
+    SgParams s{};
+    if (!c->have_sg) return s;
+    s.W = c->sg.W; s.P = c->sg.P; s.H = c->sg.H; s.stride = c->sg.stride;
+    s.tab = c->sg.tab.as<double>();
+    s.sym = c->sg.sym.as<uint8_t>();
+    s.int_ok = c->sg.int_ok;
+    s.itab = c->sg.itab.as<int32_t>();
+    s.den = c->sg.den; s.den_edge = c->sg.den_edge;
+    s.guard = c->sg.guard; s.guard_edge = c->sg.guard_edge;
+    s.rden = c->sg.rden; s.rden_edge = c->sg.rden_edge;
+    return s;
+}
+
+static int need_source(wfa_ctx* c, int source) {
+    if (!c->have_records) return fail(WFA_E_STATE, "records not uploaded");
+    switch (source) {
+        case WFA_SRC_RAW:
+            if (!c->have_u16) return fail(WFA_E_STATE, "wave_pool (uint16) not uploaded");
+            return WFA_OK;
+        case WFA_SRC_F32:
+            if (!c->have_f32) return fail(WFA_E_STATE, "wave_pool_filtered (float32) not resident");
+            return WFA_OK;
+        case WFA_SRC_SG_FUSED:
+            if (!c->have_u16) return fail(WFA_E_STATE, "wave_pool (uint16) not uploaded");
+            if (!c->have_sg) return fail(WFA_E_STATE, "Savitzky-Golay plan not set");
+            return WFA_OK;
+        default:
+            return fail(WFA_E_INVALID, "unknown wave source %d", source);
+    }
+}
+
+static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int32_t bl_end,
+                    int32_t le, int32_t re, int32_t max_len, int64_t* n_hits) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, source))) return rc;
+    if (!n_hits) return fail(WFA_E_INVALID, "n_hits is null");
+    if (le < 0) le = 0;  // hit_finder.py:124-125
+    if (re < 0) re = 0;
+    if (max_len <= 0) max_len = c->max_len;
+    if (max_len < c->max_len)
+        return fail(WFA_E_INVALID, "max_len (%d) < longest uploaded record (%d)", max_len, c->max_len);
+    if (fused_bl && bl_start < 0) return fail(WFA_E_INVALID, "baseline window start must be >= 0");
+    c->n_hits = -1;
+    if (c->R == 0) {
+        c->n_hits = 0;
+        *n_hits = 0;
+        return WFA_OK;
+    }
+
+    const int64_t R = c->R;
+    if ((rc = c->rec_tmp_start.ensure(R * sizeof(int64_t)))) return rc;
+    if ((rc = c->rec_nhits.ensure(R * sizeof(int32_t)))) return rc;
+    if ((rc = c->rec_out_start.ensure(R * sizeof(int64_t)))) return rc;
+    const int64_t nb = scan_blocks_for(R);
+    if ((rc = c->scan_blocks.ensure((nb + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = c->cursor.ensure(sizeof(unsigned long long)))) return rc;
+
+    HitParams hp{};
+    hp.le = le; hp.re = re; hp.max_len = max_len;
+    hp.bl_start = bl_start; hp.bl_end = bl_end;
+    hp.bm_words = (c->max_len + 63) / 64 + 1;
+    hp.chunk_rows = 256;
+    const int64_t waves = hits_waves(R);
+    int64_t want_rows = waves * hp.chunk_rows + c->pool_n / 256 + 4096;
+    if (c->hit_tmp_rows < want_rows) {
+        if ((rc = c->hit_tmp.ensure((size_t)want_rows * 60))) return rc;
+        c->hit_tmp_rows = want_rows;
+    }
+
+    const PoolView pv = pool_view(c);
+    const RecView rv = rec_view(c);
+    const SgParams sp = sg_params(c);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        hp.tmp = c->hit_tmp.as<uint8_t>();
+        hp.tmp_rows = c->hit_tmp_rows;
+        hp.cursor = c->cursor.as<unsigned long long>();
+        hp.rec_tmp_start = c->rec_tmp_start.as<int64_t>();
+        hp.rec_nhits = c->rec_nhits.as<int32_t>();
+        WFA_HIP_CHECK(hipMemsetAsync(c->cursor.ptr, 0, sizeof(unsigned long long), c->stream));
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_hits(c->stream, source, fused_bl, pv, rv, sp, hp));
+            const char* name = source == WFA_SRC_SG_FUSED
+                                   ? (fused_bl ? "k_hits<sg_fused,baseline>" : "k_hits<sg_fused>")
+                                   : (source == WFA_SRC_F32 ? "k_hits<f32>" : (fused_bl ? "k_hits<raw,baseline>" : "k_hits<raw>"));
+            if ((rc = t.end(name))) return rc;
+        }
+        unsigned long long used = 0;
+        WFA_HIP_CHECK(hipMemcpyAsync(&used, c->cursor.ptr, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if ((int64_t)used <= c->hit_tmp_rows) break;
+        if (attempt == 1) return fail(WFA_E_NOMEM, "hit scratch overflow after regrow");
+        // chunk placement is deterministic for a fixed grid: `used` rows are enough
+        const int64_t rows = (int64_t)used + 1024;
+        if ((rc = c->hit_tmp.ensure((size_t)rows * 60))) return rc;
+        c->hit_tmp_rows = rows;
+    }
+
+    {
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_scan(c->stream, c->rec_nhits.as<int32_t>(), R, c->scan_blocks.as<int64_t>(),
+                                  c->rec_out_start.as<int64_t>()));
+        if ((rc = t.end("k_scan(hit counts)"))) return rc;
+    }
+    int64_t total = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&total, c->scan_blocks.as<int64_t>() + nb, sizeof(int64_t),
+                                 hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if ((rc = c->hit_out.ensure((size_t)total * 60))) return rc;
+    {
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_hits_gather(c->stream, c->hit_tmp.as<uint8_t>(), c->rec_tmp_start.as<int64_t>(),
+                                         c->rec_nhits.as<int32_t>(), c->rec_out_start.as<int64_t>(), R,
+                                         c->hit_out.as<uint8_t>()));
+        if ((rc = t.end("k_hits_gather"))) return rc;
+    }
+    c->n_hits = total;
+    *n_hits = total;
+    return WFA_OK;
+}
+
+}  // namespace wfa
+
+using namespace wfa;
+
+extern "C" {
+
+int wfa_abi_version(void) { return WFA_ABI_VERSION; }
+
+int wfa_device_count(int* count) {
+    if (!count) return fail(WFA_E_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(WFA_E_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return WFA_OK;
+}
+
+int wfa_last_error(char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0) return WFA_E_INVALID;
+    snprintf(buf, buf_len, "%s", g_last_error.c_str());
+    return WFA_OK;
+}
+
+int wfa_ctx_create(int device_id, wfa_ctx** out) {
+    if (!out) return fail(WFA_E_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    WFA_HIP_CHECK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail(WFA_E_INVALID, "device %d out of range (have %d)", device_id, n);
+    WFA_HIP_CHECK(hipSetDevice(device_id));
+    wfa_ctx* c = new (std::nothrow) wfa_ctx();
+    if (!c) return fail(WFA_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        wfa_ctx_destroy(c);
+        return fail(WFA_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return WFA_OK;
+}
+
+void wfa_ctx_destroy(wfa_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)wfa_rccl_destroy(c);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
+                      &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->sg.tab,
+                      &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
+                      &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
+    for (DevBuf* b : bufs) b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int wfa_sync(wfa_ctx* c) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_upload_pool_u16(wfa_ctx* c, const uint16_t* pool, int64_t n) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !pool)) return fail(WFA_E_INVALID, "bad wave_pool argument");
+    if ((rc = h2d(c, c->pool_u16, pool, (size_t)n * sizeof(uint16_t)))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->pool_n = n;
+    c->have_u16 = true;
+    c->have_f32 = false;  // a filtered pool belongs to the previous wave_pool
+    c->have_records = false;
+    return WFA_OK;
+}
+
+int wfa_upload_pool_f32(wfa_ctx* c, const float* pool, int64_t n) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !pool)) return fail(WFA_E_INVALID, "bad wave_pool_filtered argument");
+    if (c->have_u16 && n != c->pool_n)
+        return fail(WFA_E_INVALID, "wave_pool_filtered has %lld samples, wave_pool has %lld",
+                    (long long)n, (long long)c->pool_n);
+    if ((rc = h2d(c, c->pool_f32, pool, (size_t)n * sizeof(float)))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!c->have_u16) {
+        c->pool_n = n;
+        c->have_records = false;
+    }
+    c->have_f32 = true;
+    return WFA_OK;
+}
+
+int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int32_t* len,
+                           const double* baseline, const int8_t* pol, const double* thr,
+                           const int64_t* ts, const int32_t* dt, const int16_t* board,
+                           const int16_t* chan, const int64_t* rid) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (!c->have_u16 && !c->have_f32) return fail(WFA_E_STATE, "upload a pool before the records");
+    if (R < 0) return fail(WFA_E_INVALID, "negative record count");
+    if (R > 0 && (!off || !len || !baseline || !pol || !thr || !ts || !dt || !board || !chan || !rid))
+        return fail(WFA_E_INVALID, "null records column");
+    int32_t max_len = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        // same checks, same wording as data/records_view.py:47-56
+        if (off[r] < 0) return fail(WFA_E_INVALID, "records contain negative wave_offset values");
+        if (len[r] < 0) return fail(WFA_E_INVALID, "records contain negative event_length values");
+        if (off[r] + (int64_t)len[r] > c->pool_n)
+            return fail(WFA_E_INVALID, "records reference samples outside wave_pool bounds");
+        if (len[r] > WFA_MAX_RECORD_SAMPLES)
+            return fail(WFA_E_LIMIT, "record %lld has %d samples; this build supports at most %d",
+                        (long long)r, len[r], WFA_MAX_RECORD_SAMPLES);
+        if (pol[r] < WFA_POL_UNKNOWN || pol[r] > WFA_POL_POSITIVE)
+            return fail(WFA_E_INVALID, "bad polarity code %d at record %lld", (int)pol[r], (long long)r);
+        if (len[r] > max_len) max_len = len[r];
+    }
+    const size_t n = (size_t)R;
+    if ((rc = h2d(c, c->off, off, n * 8))) return rc;
+    if ((rc = h2d(c, c->len, len, n * 4))) return rc;
+    if ((rc = h2d(c, c->baseline, baseline, n * 8))) return rc;
+    if ((rc = h2d(c, c->pol, pol, n))) return rc;
+    if ((rc = h2d(c, c->thr, thr, n * 8))) return rc;
+    if ((rc = h2d(c, c->ts, ts, n * 8))) return rc;
+    if ((rc = h2d(c, c->dt, dt, n * 4))) return rc;
+    if ((rc = h2d(c, c->board, board, n * 2))) return rc;
+    if ((rc = h2d(c, c->chan, chan, n * 2))) return rc;
+    if ((rc = h2d(c, c->rid, rid, n * 8))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->R = R;
+    c->max_len = max_len;
+    c->have_records = true;
+    c->n_hits = -1;
+    return WFA_OK;
+}
+
+int wfa_set_sg_plan(wfa_ctx* c, int window, int polyorder, const double* tab, const uint8_t* symmetric,
+                    int int_ok, const int32_t* itab, int32_t den, int32_t den_edge, int64_t guard,
+                    int64_t guard_edge) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (window < 1 || (window & 1) == 0 || window > WFA_MAX_SG_WINDOW)
+        return fail(WFA_E_INVALID, "Savitzky-Golay window must be odd and in [1, %d], got %d",
+                    WFA_MAX_SG_WINDOW, window);
+    if (polyorder < 0 || polyorder >= window)
+        return fail(WFA_E_INVALID, "polyorder %d must be in [0, window)", polyorder);
+    if (!tab || !symmetric) return fail(WFA_E_INVALID, "null plan table");
+    if (int_ok && (!itab || den <= 0 || den_edge <= 0)) return fail(WFA_E_INVALID, "bad integer plan");
+    SgPlanDev& s = c->sg;
+    s.W = window; s.P = polyorder; s.H = window / 2;
+    s.n_tables = (window + 1) / 2;
+    s.stride = window + 2 * s.H * window;
+    s.int_ok = int_ok ? 1 : 0;
+    s.den = int_ok ? den : 1;
+    s.den_edge = int_ok ? den_edge : 1;
+    s.guard = guard; s.guard_edge = guard_edge;
+    s.rden = 1.0 / (double)s.den;
+    s.rden_edge = 1.0 / (double)s.den_edge;
+    if ((rc = h2d(c, s.tab, tab, (size_t)s.n_tables * s.stride * sizeof(double)))) return rc;
+    if ((rc = h2d(c, s.sym, symmetric, (size_t)s.n_tables))) return rc;
+    const size_t isz = (size_t)s.stride * sizeof(int32_t);
+    if (int_ok) {
+        if ((rc = h2d(c, s.itab, itab, isz))) return rc;
+    } else {
+        if ((rc = s.itab.ensure(isz))) return rc;
+    }
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->have_sg = true;
+    return WFA_OK;
+}
+
+int wfa_baseline_mean(wfa_ctx* c, int32_t start, int32_t end, int update_records, double* out) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, WFA_SRC_RAW))) return rc;
+    if (start < 0) return fail(WFA_E_INVALID, "baseline window start must be >= 0");
+    if (c->R == 0) return WFA_OK;
+    double* dst = c->baseline.as<double>();
+    if (!update_records) {
+        if ((rc = c->out_rows.ensure((size_t)c->R * sizeof(double)))) return rc;
+        dst = c->out_rows.as<double>();
+    }
+    {
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_baseline_mean(c->stream, pool_view(c), rec_view(c), start, end, dst));
+        if ((rc = t.end("k_baseline_mean"))) return rc;
+    }
+    if (out)
+        WFA_HIP_CHECK(hipMemcpyAsync(out, dst, (size_t)c->R * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_savgol(wfa_ctx* c, float* out) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, WFA_SRC_SG_FUSED))) return rc;
+    if ((rc = c->pool_f32.ensure((size_t)c->pool_n * sizeof(float)))) return rc;
+    // gaps between records stay 0.0 (records.py:382)
+    WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
+    if (c->R > 0) {
+        PoolView pv = pool_view(c);
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_savgol(c->stream, pv, rec_view(c), sg_params(c), c->pool_f32.as<float>()));
+        if ((rc = t.end("k_savgol"))) return rc;
+    }
+    c->have_f32 = true;
+    if (out)
+        WFA_HIP_CHECK(hipMemcpyAsync(out, c->pool_f32.ptr, (size_t)c->pool_n * sizeof(float),
+                                     hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_threshold_hits_count(wfa_ctx* c, int source, int32_t le, int32_t re, int32_t max_len,
+                             int64_t* n_hits) {
+    return run_hits(c, source, false, 0, 0, le, re, max_len, n_hits);
+}
+
+int wfa_fused_baseline_filter_hits(wfa_ctx* c, int32_t bl_start, int32_t bl_end, int32_t le, int32_t re,
+                                   int32_t max_len, int64_t* n_hits) {
+    return run_hits(c, WFA_SRC_SG_FUSED, bl_end > bl_start, bl_start, bl_end, le, re, max_len, n_hits);
+}
+
+int wfa_threshold_hits_fill(wfa_ctx* c, void* out_rows, int64_t n_hits) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (c->n_hits < 0) return fail(WFA_E_STATE, "no hit pass has been run");
+    if (n_hits != c->n_hits)
+        return fail(WFA_E_INVALID, "caller expects %lld rows, the pass produced %lld", (long long)n_hits,
+                    (long long)c->n_hits);
+    if (n_hits == 0) return WFA_OK;
+    if (!out_rows) return fail(WFA_E_INVALID, "out_rows is null");
+    WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->hit_out.ptr, (size_t)n_hits * 60, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_basic_features(wfa_ctx* c, int source, int64_t h0, int64_t h1, int h_has_end, int64_t a0,
+                       int64_t a1, int a_has_end, const double* fixed_baseline, void* out_rows) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, source))) return rc;
+    if (c->R == 0) return WFA_OK;
+    if (!out_rows) return fail(WFA_E_INVALID, "out_rows is null");
+    FeatParams fp{};
+    fp.h0 = h0; fp.h1 = h1; fp.h_has_end = h_has_end;
+    fp.a0 = a0; fp.a1 = a1; fp.a_has_end = a_has_end;
+    fp.fixed_bl = nullptr;
+    if (fixed_baseline) {
+        if ((rc = h2d(c, c->fixed_bl, fixed_baseline, (size_t)c->R * sizeof(double)))) return rc;
+        fp.fixed_bl = c->fixed_bl.as<double>();
+    }
+    if ((rc = c->out_rows.ensure((size_t)c->R * 36))) return rc;
+    {
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_basic_features(c->stream, source, pool_view(c), rec_view(c), sg_params(c), fp,
+                                            c->out_rows.as<uint8_t>()));
+        if ((rc = t.end("k_basic_features"))) return rc;
+    }
+    WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 36, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_width_integral(wfa_ctx* c, int source, double q_low, double q_high, double dt, void* out_rows) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, source))) return rc;
+    if (!(q_low > 0.0) || !(q_high < 1.0) || !(q_low < q_high))  // waveform_width_integral.py:95-96
+        return fail(WFA_E_INVALID, "q_low/q_high invalid: q_low=%g, q_high=%g", q_low, q_high);
+    if (c->R == 0) return WFA_OK;
+    if (!out_rows) return fail(WFA_E_INVALID, "out_rows is null");
+    WidthParams wp{q_low, q_high, dt};
+    int rc2 = c->out_rows.ensure((size_t)c->R * 52);
+    if (rc2) return rc2;
+    {
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_width_integral(c->stream, source, pool_view(c), rec_view(c), sg_params(c), wp,
+                                            c->out_rows.as<uint8_t>()));
+        if ((rc = t.end("k_width_integral"))) return rc;
+    }
+    WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 52, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_profile_enable(wfa_ctx* c, int on) {
+    if (!c) return fail(WFA_E_INVALID, "null context");
+    c->prof_on = on != 0;
+    return WFA_OK;
+}
+
+int wfa_profile_reset(wfa_ctx* c) {
+    if (!c) return fail(WFA_E_INVALID, "null context");
+    c->prof.clear();
+    return WFA_OK;
+}
+
+int wfa_profile_get(wfa_ctx* c, int idx, char* name, size_t name_len, double* total_ms, int64_t* launches) {
+    if (!c) return fail(WFA_E_INVALID, "null context");
+    if (idx < 0 || idx >= (int)c->prof.size()) return WFA_E_INVALID;
+    const ProfEntry& e = c->prof[idx];
+    if (name && name_len) snprintf(name, name_len, "%s", e.name.c_str());
+    if (total_ms) *total_ms = e.total_ms;
+    if (launches) *launches = e.launches;
+    return WFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Shared host-side definitions of libwfa_hip.so (context, error handling, buffer helpers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wfa_hip.h"
+
+namespace wfa {
+
+extern thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...);
+
+#define WFA_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return ::wfa::fail(WFA_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                          \
+    } while (0)
+
+// Growable device buffer.
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);  // keeps contents only if no growth is needed
+    void release();
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(ptr);
+    }
+};
+
+struct ProfEntry {
+    std::string name;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct SgPlanDev {
+    int W = 0, P = 0, H = 0;
+    int n_tables = 0;
+    int stride = 0;   // doubles per table
+    int int_ok = 0;
+    int32_t den = 1, den_edge = 1;
+    int64_t guard = 0, guard_edge = 0;
+    double rden = 1.0, rden_edge = 1.0;
+    DevBuf tab;   // double
+    DevBuf itab;  // int32
+    DevBuf sym;   // uint8
+    std::vector<uint8_t> sym_host;
+};
+
+}  // namespace wfa
+
+struct wfa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // resident pool
+    wfa::DevBuf pool_u16;
+    wfa::DevBuf pool_f32;
+    int64_t pool_n = 0;
+    bool have_u16 = false, have_f32 = false;
+
+    // records SoA
+    int64_t R = 0;
+    int32_t max_len = 0;
+    bool have_records = false;
+    wfa::DevBuf off, len, baseline, pol, thr, ts, dt, board, chan, rid, fixed_bl;
+
+    wfa::SgPlanDev sg;
+    bool have_sg = false;
+
+    // hit scratch
+    wfa::DevBuf hit_tmp;        // 60 B rows in chunk order
+    int64_t hit_tmp_rows = 0;
+    wfa::DevBuf cursor;         // unsigned long long
+    wfa::DevBuf rec_tmp_start;  // int64 per record
+    wfa::DevBuf rec_nhits;      // int32 per record
+    wfa::DevBuf rec_out_start;  // int64 per record
+    wfa::DevBuf scan_blocks;    // int64 per scan block
+    wfa::DevBuf hit_out;        // final rows
+    int64_t n_hits = -1;
+
+    wfa::DevBuf out_rows;  // per-record feature rows
+
+    // profiling
+    bool prof_on = false;
+    std::vector<wfa::ProfEntry> prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // rccl (opaque, owned by wfa_rccl.hip)
+    void* comm = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+namespace wfa {
+
+// RAII-less launch timer: call begin() before the launch and end(name) after it.
+struct LaunchTimer {
+    wfa_ctx* c;
+    explicit LaunchTimer(wfa_ctx* ctx) : c(ctx) {
+        if (c->prof_on) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    int end(const char* name) {
+        if (!c->prof_on) return WFA_OK;
+        WFA_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        WFA_HIP_CHECK(hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        WFA_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        for (auto& e : c->prof)
+            if (e.name == name) {
+                e.total_ms += ms;
+                e.launches += 1;
+                return WFA_OK;
+            }
+        c->prof.push_back({name, (double)ms, 1});
+        return WFA_OK;
+    }
+};
+
+}  // namespace wfa

@@ -1,0 +1,86 @@
+// Kernel parameter blocks and launchers (implemented in wfa_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "wfa_hip.h"
+
+namespace wfa {
+
+struct PoolView {
+    const uint16_t* u16;
+    const float* f32;
+    int64_t n;
+};
+
+// Records SoA (reference row layout: core/processing/dtypes.py:80-100).
+struct RecView {
+    int64_t R;
+    const int64_t* off;
+    const int32_t* len;
+    const double* baseline;
+    double* baseline_rw;  // same column, writable (fused baseline estimate)
+    const int8_t* pol;
+    const double* thr;
+    const int64_t* ts;
+    const int32_t* dt;
+    const int16_t* board;
+    const int16_t* chan;
+    const int64_t* rid;
+};
+
+struct SgParams {
+    int W, P, H;
+    int stride;  // doubles per table
+    const double* tab;
+    const uint8_t* sym;
+    int int_ok;
+    const int32_t* itab;
+    int32_t den, den_edge;
+    int64_t guard, guard_edge;
+    double rden, rden_edge;
+};
+
+struct HitParams {
+    int32_t le, re, max_len;
+    int32_t bl_start, bl_end;
+    int32_t bm_words;  // LDS words per wave
+    int32_t chunk_rows;
+    uint8_t* tmp;
+    int64_t tmp_rows;
+    unsigned long long* cursor;
+    int64_t* rec_tmp_start;
+    int32_t* rec_nhits;
+};
+
+struct FeatParams {
+    int64_t h0, h1, a0, a1;
+    int h_has_end, a_has_end;
+    const double* fixed_bl;  // nullable
+};
+
+struct WidthParams {
+    double q_low, q_high, dt;
+};
+
+hipError_t launch_baseline_mean(hipStream_t st, const PoolView& pool, const RecView& rec,
+                                int32_t start, int32_t end, double* out);
+hipError_t launch_savgol(hipStream_t st, const PoolView& pool, const RecView& rec,
+                         const SgParams& sg, float* out);
+int hits_grid(int64_t R);
+int hits_waves(int64_t R);
+hipError_t launch_hits(hipStream_t st, int source, bool fused_baseline, const PoolView& pool,
+                       const RecView& rec, const SgParams& sg, const HitParams& hp);
+int64_t scan_blocks_for(int64_t n);
+hipError_t launch_scan(hipStream_t st, const int32_t* counts, int64_t n, int64_t* block_sums,
+                       int64_t* out);
+hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t* tmp_start,
+                              const int32_t* nhits, const int64_t* out_start, int64_t R, uint8_t* out);
+hipError_t launch_basic_features(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
+                                 const SgParams& sg, const FeatParams& fp, uint8_t* out);
+hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
+                                 const SgParams& sg, const WidthParams& wp, uint8_t* out);
+
+}  // namespace wfa

@@ -1,0 +1,292 @@
+"""DeviceSession: one wfa_ctx (one GPU, one HIP stream) with a resident pool + records SoA.
+
+Host-side mirror of the reference's RecordsView input contract
+(waveform_analysis/core/data/records_view.py:16-56): validates the records table, converts it
+to the structure-of-arrays the kernels read, and exposes one method per kernel.  All compute
+happens in libwfa_hip.so; nothing here falls back to numpy.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from .dtypes import (
+    BASIC_FEATURES_DTYPE,
+    THRESHOLD_HIT_DTYPE,
+    WAVEFORM_WIDTH_INTEGRAL_DTYPE,
+)
+from .sg_plan import SgPlan, build_plan
+
+REQUIRED_RECORD_FIELDS = ("record_id", "wave_offset", "event_length", "timestamp", "baseline")
+
+
+def _ptr(arr: np.ndarray | None):
+    return None if arr is None else arr.ctypes.data_as(C.c_void_p)
+
+
+def _col(records: np.ndarray, name: str, dtype, default=None) -> np.ndarray:
+    names = records.dtype.names or ()
+    if name in names:
+        return np.ascontiguousarray(records[name], dtype=dtype)
+    if default is None:
+        raise ValueError(f"records missing required fields: ['{name}']")
+    return np.full(len(records), default, dtype=dtype)
+
+
+def polarity_codes(records: np.ndarray) -> np.ndarray:
+    """'positive'/'negative'/anything else -> WFA_POL_* (records["polarity"], dtypes.py:87)."""
+    out = np.zeros(len(records), dtype=np.int8)
+    if "polarity" in (records.dtype.names or ()):
+        pol = np.asarray(records["polarity"]).astype("U16")
+        out[pol == "negative"] = _lib.POL_NEGATIVE
+        out[pol == "positive"] = _lib.POL_POSITIVE
+    return out
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _lib.check(_lib.load().wfa_device_count(C.byref(n)))
+    return int(n.value)
+
+
+class DeviceSession:
+    """Owns a wfa_ctx.  Not thread-safe: use one session per thread (see device_pool)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = _lib.load()
+        handle = C.c_void_p()
+        _lib.check(self._lib.wfa_ctx_create(int(device_id), C.byref(handle)))
+        self._h = handle
+        self.device_id = int(device_id)
+        self.n_records = 0
+        self.n_samples = 0
+        self.max_len = 0
+        self._plan: SgPlan | None = None
+        self._keep: list = []  # host arrays referenced by in-flight calls
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.wfa_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- resident inputs ------------------------------------------------------------------------
+    def upload_pool(self, wave_pool: np.ndarray) -> None:
+        """wave_pool (uint16) or wave_pool_filtered (float32); read-only memmaps are fine."""
+        if not isinstance(wave_pool, np.ndarray) or wave_pool.ndim != 1:
+            raise ValueError("wave_pool must be a 1-D numpy array")
+        if wave_pool.dtype == np.uint16:
+            arr = np.ascontiguousarray(wave_pool)
+            _lib.check(self._lib.wfa_upload_pool_u16(self._h, _ptr(arr), arr.size))
+        elif wave_pool.dtype == np.float32:
+            arr = np.ascontiguousarray(wave_pool)
+            _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
+        else:
+            raise ValueError(f"wave_pool dtype must be uint16 or float32, got {wave_pool.dtype}")
+        self.n_samples = int(wave_pool.size)
+
+    def upload_filtered_pool(self, pool_f32: np.ndarray) -> None:
+        arr = np.ascontiguousarray(pool_f32, dtype=np.float32)
+        _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
+
+    def upload_records(self, records: np.ndarray, thresholds: np.ndarray | float = 10.0) -> None:
+        if records.dtype.names is None:
+            raise ValueError("records must be a structured array")
+        missing = [n for n in REQUIRED_RECORD_FIELDS if n not in records.dtype.names]
+        if missing:
+            raise ValueError(f"records missing required fields: {missing}")
+        n = len(records)
+        rid = _col(records, "record_id", np.int64)
+        if n and len(np.unique(rid)) != n:
+            dup = rid[np.flatnonzero(np.diff(np.sort(rid)) == 0)[0]] if n > 1 else rid[0]
+            raise ValueError(f"records field record_id must be unique, got duplicate {int(dup)}")
+        thr = np.ascontiguousarray(np.broadcast_to(np.asarray(thresholds, dtype=np.float64), (n,)))
+        cols = [
+            _col(records, "wave_offset", np.int64),
+            _col(records, "event_length", np.int32),
+            _col(records, "baseline", np.float64),
+            polarity_codes(records),
+            thr,
+            _col(records, "timestamp", np.int64),
+            _col(records, "dt", np.int32, default=1),
+            _col(records, "board", np.int16, default=0),
+            _col(records, "channel", np.int16, default=0),
+            rid,
+        ]
+        _lib.check(self._lib.wfa_upload_records_soa(self._h, n, *[_ptr(c) for c in cols]))
+        self.n_records = n
+        self.max_len = int(cols[1].max()) if n else 0
+
+    def set_sg_plan(self, sg_window_size: int = 11, sg_poly_order: int = 2) -> SgPlan:
+        plan = build_plan(int(sg_window_size), int(sg_poly_order))
+        _lib.check(
+            self._lib.wfa_set_sg_plan(
+                self._h, plan.window, plan.polyorder, _ptr(plan.tab), _ptr(plan.symmetric),
+                int(plan.int_ok), _ptr(plan.itab), plan.den, plan.den_edge, plan.guard, plan.guard_edge,
+            )
+        )
+        self._plan = plan
+        return plan
+
+    # -- kernels --------------------------------------------------------------------------------
+    def baseline_mean(self, start: int, end: int, update_records: bool = False) -> np.ndarray:
+        out = np.empty(self.n_records, dtype=np.float64)
+        _lib.check(self._lib.wfa_baseline_mean(self._h, int(start), int(end), int(update_records), _ptr(out)))
+        return out
+
+    def savgol(self, download: bool = True) -> np.ndarray | None:
+        out = np.empty(self.n_samples, dtype=np.float32) if download else None
+        _lib.check(self._lib.wfa_savgol(self._h, _ptr(out)))
+        return out
+
+    def _fill_hits(self, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=THRESHOLD_HIT_DTYPE)
+        _lib.check(self._lib.wfa_threshold_hits_fill(self._h, _ptr(out), n))
+        return out
+
+    def threshold_hits(self, source: int = _lib.SRC_RAW, left_extension: int = 2, right_extension: int = 2,
+                       max_len: int = 0, download: bool = True) -> np.ndarray | int:
+        n = C.c_int64(0)
+        _lib.check(self._lib.wfa_threshold_hits_count(self._h, int(source), int(left_extension),
+                                                      int(right_extension), int(max_len), C.byref(n)))
+        return self._fill_hits(int(n.value)) if download else int(n.value)
+
+    def fused_baseline_filter_hits(self, baseline_window: tuple[int, int] = (0, 0), left_extension: int = 2,
+                                   right_extension: int = 2, max_len: int = 0,
+                                   download: bool = True) -> np.ndarray | int:
+        n = C.c_int64(0)
+        _lib.check(self._lib.wfa_fused_baseline_filter_hits(
+            self._h, int(baseline_window[0]), int(baseline_window[1]), int(left_extension),
+            int(right_extension), int(max_len), C.byref(n)))
+        return self._fill_hits(int(n.value)) if download else int(n.value)
+
+    def basic_features(self, source: int = _lib.SRC_RAW, height_range=(40, 90), area_range=(0, None),
+                       fixed_baseline: np.ndarray | None = None) -> np.ndarray:
+        out = np.zeros(self.n_records, dtype=BASIC_FEATURES_DTYPE)
+        h0, h1 = height_range
+        a0, a1 = area_range
+        fb = None if fixed_baseline is None else np.ascontiguousarray(fixed_baseline, dtype=np.float64)
+        if fb is not None and len(fb) != self.n_records:
+            raise ValueError("fixed_baseline must have one entry per record")
+        _lib.check(self._lib.wfa_basic_features(
+            self._h, int(source), int(h0 or 0), int(h1 or 0), int(h1 is not None),
+            int(a0 or 0), int(a1 or 0), int(a1 is not None), _ptr(fb), _ptr(out)))
+        return out
+
+    def width_integral(self, source: int = _lib.SRC_RAW, q_low: float = 0.1, q_high: float = 0.9,
+                       dt: float = 2.0) -> np.ndarray:
+        out = np.zeros(self.n_records, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)
+        _lib.check(self._lib.wfa_width_integral(self._h, int(source), float(q_low), float(q_high),
+                                                float(dt), _ptr(out)))
+        return out
+
+    def sync(self) -> None:
+        _lib.check(self._lib.wfa_sync(self._h))
+
+    # -- measurement ----------------------------------------------------------------------------
+    def profile(self, on: bool = True) -> None:
+        _lib.check(self._lib.wfa_profile_enable(self._h, int(on)))
+        _lib.check(self._lib.wfa_profile_reset(self._h))
+
+    def profile_report(self) -> dict[str, tuple[float, int]]:
+        out = {}
+        name = C.create_string_buffer(128)
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        idx = 0
+        while self._lib.wfa_profile_get(self._h, idx, name, len(name), C.byref(ms), C.byref(cnt)) == 0:
+            out[name.value.decode()] = (float(ms.value), int(cnt.value))
+            idx += 1
+        return out
+
+    # -- RCCL -----------------------------------------------------------------------------------
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().wfa_rccl_unique_id(buf))
+        return buf.raw
+
+    def rccl_init(self, rank: int, n_ranks: int, unique_id: bytes) -> None:
+        buf = C.create_string_buffer(unique_id, 128)
+        _lib.check(self._lib.wfa_rccl_init(self._h, int(rank), int(n_ranks), buf))
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+
+    def rccl_gather_rows(self, rows: np.ndarray | None, n_rows: int, row_dtype: np.dtype, root: int = 0):
+        """Gather structured rows from all ranks to `root` (rank order).  rows=None sends the
+        device-resident hit rows of the last hit pass.  Returns (counts, rows-or-None)."""
+        row_dtype = np.dtype(row_dtype)
+        counts = np.zeros(self.n_ranks, dtype=np.int64)
+        _lib.check(self._lib.wfa_rccl_allgather_counts(self._h, int(n_rows), _ptr(counts)))
+        out = np.empty(int(counts.sum()), dtype=row_dtype) if self.rank == root else None
+        src = None if rows is None else np.ascontiguousarray(rows)
+        _lib.check(self._lib.wfa_rccl_gather_rows(self._h, _ptr(src), int(n_rows), row_dtype.itemsize,
+                                                  int(root), _ptr(counts), _ptr(out)))
+        return counts, out
+
+
+# ---- device pool for the streaming dispatcher ----------------------------------------------------
+class DevicePool:
+    """Round-robin pool of sessions: one per (GPU, worker thread).
+
+    The reference dispatches chunks to an ExecutorManager thread pool
+    (waveform_analysis/core/plugins/core/streaming.py:740-860); here each worker thread borrows
+    the session bound to it, so chunk k runs on GPU k mod n_devices on its own HIP stream.
+    """
+
+    def __init__(self, device_ids: list[int] | None = None):
+        ids = list(device_ids) if device_ids is not None else list(range(max(device_count(), 1)))
+        if not ids:
+            raise _lib.WfaError(_lib.WFA_E_HIP, "no HIP device visible")
+        self.device_ids = ids
+        self._local = threading.local()
+        self._lock = threading.Lock()
+        self._next = 0
+        self._all: list[DeviceSession] = []
+
+    def session(self) -> DeviceSession:
+        s = getattr(self._local, "session", None)
+        if s is None:
+            with self._lock:
+                dev = self.device_ids[self._next % len(self.device_ids)]
+                self._next += 1
+            s = DeviceSession(dev)
+            self._local.session = s
+            with self._lock:
+                self._all.append(s)
+        return s
+
+    def close(self) -> None:
+        with self._lock:
+            for s in self._all:
+                s.close()
+            self._all.clear()
+
+
+_default_pool: DevicePool | None = None
+_default_lock = threading.Lock()
+
+
+def default_pool() -> DevicePool:
+    global _default_pool
+    with _default_lock:
+        if _default_pool is None:
+            _default_pool = DevicePool()
+        return _default_pool
+
+
+__all__ = ["DeviceSession", "DevicePool", "default_pool", "device_count", "polarity_codes"]

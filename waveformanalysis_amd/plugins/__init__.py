@@ -1,0 +1,20 @@
+"""HIP drop-in plugins for the records-backed hot path.
+
+``hip_default()`` is the packaging the reference uses for backends: a profile function
+returning plugin instances (waveform_analysis/core/plugins/profiles.py:20-62); register them
+with ``ctx.register(p, allow_override=True)`` to replace the CPU plugins of the same name.
+"""
+
+from .basic_features import HipBasicFeaturesPlugin
+from .threshold_hit import HipThresholdHitPlugin
+from .wave_pool_filtered import HipWavePoolFilteredPlugin
+from .width_integral import HipWaveformWidthIntegralPlugin
+
+
+def hip_default():
+    return [HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
+            HipWaveformWidthIntegralPlugin()]
+
+
+__all__ = ["HipWavePoolFilteredPlugin", "HipThresholdHitPlugin", "HipBasicFeaturesPlugin",
+           "HipWaveformWidthIntegralPlugin", "hip_default"]

@@ -1,0 +1,167 @@
+"""Host glue shared by the HIP plugins: input loading, dt rules, per-channel options, residency.
+
+Mirrors (does not import) the reference helpers:
+  cpu/_wave_source.py:93-227   wave_source / use_filtered -> dependencies and pool name
+  cpu/_dt_compat.py:14-81      dt resolution and validation messages
+  data/records_view.py:383-400 records_view() type checks
+"""
+
+from __future__ import annotations
+
+import threading
+import warnings
+from typing import Any
+
+import numpy as np
+
+from .. import _lib
+from ..channel_config import per_record_option, scatter_per_record
+from ..device import DeviceSession, default_pool
+
+WAVE_SOURCE_AUTO = "auto"
+WAVE_SOURCE_RECORDS = "records"
+WAVE_SOURCES = {"auto", "records", "st_waveforms", "filtered_waveforms"}
+
+
+def normalize_wave_source(value: Any) -> str:
+    if value is None:
+        return WAVE_SOURCE_AUTO
+    source = str(value).strip().lower()
+    if source not in WAVE_SOURCES:
+        raise ValueError(f"Invalid wave_source: {value!r}. Expected one of {sorted(WAVE_SOURCES)}.")
+    return source
+
+
+def records_dependencies(context: Any, plugin: Any) -> tuple[list[str], str]:
+    """Dependencies and pool name for the records source (cpu/_wave_source.py:93-140).
+
+    The HIP plugins are records-backed: wave_source must be "records" (their default) --
+    the dense st_waveforms / filtered_waveforms sources stay with the CPU plugins.
+    """
+    source = normalize_wave_source(context.get_config(plugin, "wave_source"))
+    if source != WAVE_SOURCE_RECORDS:
+        raise ValueError(
+            f"{plugin.provides} (HIP backend) reads records + wave_pool; set wave_source='records' "
+            f"(got {source!r})."
+        )
+    use_filtered = bool(context.get_config(plugin, "use_filtered")) if "use_filtered" in plugin.options else False
+    fused = bool(context.get_config(plugin, "fuse_filter")) if "fuse_filter" in plugin.options else False
+    if use_filtered and not fused:
+        return ["records", "wave_pool_filtered"], "wave_pool_filtered"
+    return ["records", "wave_pool"], "wave_pool"
+
+
+def load_records_input(context: Any, plugin: Any, run_id: str, pool_name: str):
+    plugins = getattr(context, "_plugins", None)
+    if isinstance(plugins, dict) and plugins:
+        for name, hint in (("records", "RecordsPlugin"),
+                           (pool_name, "WavePoolFilteredPlugin" if pool_name == "wave_pool_filtered" else "WavePoolPlugin")):
+            if name not in plugins and name not in getattr(context, "_data", {}):
+                raise KeyError(f"{plugin.provides} requires '{name}' but it is not registered. "
+                               f"Register {hint} to provide '{name}'.")
+    records = context.get_data(run_id, "records")
+    pool = context.get_data(run_id, pool_name)
+    if not isinstance(records, np.ndarray):
+        raise ValueError("records_view requires formal 'records' plugin output")
+    if not isinstance(pool, np.ndarray):
+        raise ValueError(f"records_view requires formal '{pool_name}' plugin output")
+    if records.dtype.names is None:
+        raise ValueError("records must be a structured array")
+    return records, pool
+
+
+def raw_config(context: Any, plugin: Any, name: str) -> Any:
+    prov = plugin.provides
+    block = context.config.get(prov)
+    if isinstance(block, dict) and name in block:
+        return block[name]
+    if f"{prov}.{name}" in context.config:
+        return context.config[f"{prov}.{name}"]
+    return context.config.get(name)
+
+
+def resolve_dt_config(context: Any, plugin: Any, deprecated_keys=()) -> Any:
+    """cpu/_dt_compat.py:29-52."""
+    dt = raw_config(context, plugin, "dt")
+    if dt is not None:
+        return dt
+    for old in deprecated_keys:
+        legacy = raw_config(context, plugin, old)
+        if legacy is None:
+            continue
+        warnings.warn(f"[{plugin.provides}] Config '{old}' is deprecated and will be removed in a "
+                      "future release. Use 'dt' instead.", DeprecationWarning, stacklevel=3)
+        return legacy
+    return None
+
+
+def require_dt_array(data: np.ndarray, *, explicit_dt: Any, plugin_name: str, data_name: str) -> np.ndarray:
+    """cpu/_dt_compat.py:55-81."""
+    names = data.dtype.names or ()
+    if "dt" in names:
+        dt = np.asarray(data["dt"], dtype=np.int64)
+        if np.any(dt <= 0):
+            raise ValueError(f"[{plugin_name}] {data_name}.dt must be positive for every row")
+        if np.any(dt > np.iinfo(np.int32).max):
+            raise ValueError(f"[{plugin_name}] {data_name}.dt exceeds int32 range")
+        return dt.astype(np.int32)
+    if explicit_dt is None:
+        raise ValueError(f"[{plugin_name}] Input '{data_name}' is missing required field 'dt'; "
+                         "provide explicit config 'dt' for this migration period.")
+    dt_scalar = int(explicit_dt)
+    if dt_scalar <= 0:
+        raise ValueError(f"[{plugin_name}] dt must be > 0")
+    if dt_scalar > np.iinfo(np.int32).max:
+        raise ValueError(f"[{plugin_name}] dt exceeds int32 range: {dt_scalar}")
+    return np.full(len(data), dt_scalar, dtype=np.int32)
+
+
+def per_record_channel_option(records: np.ndarray, channel_config: Any, run_id: str, name: str,
+                              base_value: Any, default: float) -> np.ndarray:
+    """Resolve one option per (board, channel) and scatter it to a per-record float64 array."""
+    n = len(records)
+    names = records.dtype.names or ()
+    boards = records["board"] if "board" in names else np.zeros(n, dtype=np.int16)
+    channels = records["channel"] if "channel" in names else np.zeros(n, dtype=np.int16)
+    per = per_record_option(boards, channels, channel_config, run_id, {name: base_value})
+    values = {}
+    for key, rule in per.items():
+        v = rule.get(name, base_value)
+        values[key] = default if v is None else float(v)
+    return scatter_per_record(boards, channels, values, default)
+
+
+# ---- residency: keep the pool of a run on the GPU between plugin calls -----------------------------
+_resident = threading.local()
+
+
+def _identity(arr: np.ndarray) -> tuple:
+    return (arr.__array_interface__["data"][0], arr.size, arr.dtype.str)
+
+
+def resident_session(context: Any, pool: np.ndarray, pool_filtered: np.ndarray | None = None) -> DeviceSession:
+    """Session of this thread with `pool` uploaded (skipped when the same buffer is resident)."""
+    pool_obj = getattr(context, "wfa_device_pool", None) or default_pool()
+    sess = pool_obj.session()
+    state = getattr(_resident, "state", None)
+    if state is None or state.get("sess") is not sess:
+        state = {"sess": sess, "pool": None, "filtered": None}
+        _resident.state = state
+    ident = _identity(pool)
+    if state["pool"] != ident:
+        sess.upload_pool(pool)
+        state["pool"] = ident
+        state["filtered"] = None
+    if pool_filtered is not None:
+        fid = _identity(pool_filtered)
+        if state["filtered"] != fid:
+            sess.upload_filtered_pool(pool_filtered)
+            state["filtered"] = fid
+    return sess
+
+
+def invalidate_residency() -> None:
+    _resident.state = None
+
+
+SRC_RAW, SRC_F32, SRC_SG_FUSED = _lib.SRC_RAW, _lib.SRC_F32, _lib.SRC_SG_FUSED
