@@ -74,6 +74,7 @@ def main() -> None:
     ap.add_argument("--records", type=int, default=1_250_000, help="records per GPU (x800 = 1e9 samples)")
     ap.add_argument("--cpu-records", type=int, default=12_500, help="records in the CPU baseline slice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threshold", type=float, default=10.0, help="hit threshold (reference default 10.0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,7 +104,7 @@ def main() -> None:
     sess.upload_pool(pool)
     rec_in = records.copy()
     rec_in["baseline"] = np.nan  # the fused pass estimates it
-    sess.upload_records(rec_in, 10.0)
+    sess.upload_records(rec_in, args.threshold)
     sess.set_sg_plan(11, 2)
     h2d_s = time.perf_counter() - t0
 

@@ -1,6 +1,7 @@
 // C ABI of libwfa_hip.so (see include/wfa_hip.h): context, resident buffers, kernel calls.
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "wfa_common.hpp"
@@ -79,6 +80,7 @@ static RecView rec_view(wfa_ctx* c) {
     r.board = c->board.as<int16_t>();
     r.chan = c->chan.as<int16_t>();
     r.rid = c->rid.as<int64_t>();
+    r.bm_off = c->bm_off.as<int64_t>();
     return r;
 }
 
@@ -93,6 +95,9 @@ static SgParams sg_params(wfa_ctx* c) {
     s.den = c->sg.den; s.den_edge = c->sg.den_edge;
     s.guard = c->sg.guard; s.guard_edge = c->sg.guard_edge;
     s.rden = c->sg.rden; s.rden_edge = c->sg.rden_edge;
+    // |y| < 2^17 for uint16 samples (sum|c| < 2): float32 ulp <= 2^-7
+    s.margin = (int32_t)((c->sg.den + 127) / 128 + 2);
+    s.margin_edge = (int32_t)((c->sg.den_edge + 127) / 128 + 2);
     return s;
 }
 
@@ -141,11 +146,73 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
     if ((rc = c->scan_blocks.ensure((nb + 1) * sizeof(int64_t)))) return rc;
     if ((rc = c->cursor.ensure(sizeof(unsigned long long)))) return rc;
 
+    const PoolView pv0 = pool_view(c);
+    const RecView rv0 = rec_view(c);
+    const SgParams sp0 = sg_params(c);
+    if (source == WFA_SRC_SG_FUSED && sg_mask_supported(sp0) && !getenv("WFA_DISABLE_FAST")) {
+        // A: mask + run counts  ->  scan  ->  B1: run descriptors  ->  B2: rows (final order, no gather)
+        if (c->bitmap.cap < (size_t)c->bitmap_bytes) c->bitmap_clean = false;
+        if ((rc = c->bitmap.ensure((size_t)c->bitmap_bytes))) return rc;
+        if (!c->bitmap_clean) {  // bytes between a record's last mask byte and its next word stay zero
+            WFA_HIP_CHECK(hipMemsetAsync(c->bitmap.ptr, 0, (size_t)c->bitmap_bytes, c->stream));
+            c->bitmap_clean = true;
+        }
+        MaskParams mp{};
+        mp.bl_start = bl_start; mp.bl_end = fused_bl ? bl_end : bl_start;
+        mp.bitmap = c->bitmap.as<uint8_t>();
+        mp.rec_nhits = c->rec_nhits.as<int32_t>();
+        if (c->span_ok && c->span_L >= sp0.W && !getenv("WFA_DISABLE_SPAN")) {
+            SpanParams sp{};
+            sp.off0 = c->span_off0; sp.L = c->span_L; sp.positive = c->span_positive;
+            sp.rs = 64;
+            sp.n_spans = (R + sp.rs - 1) / sp.rs;
+            sp.bm_off0 = 0;
+            sp.bm_stride = ((int64_t)c->span_L + 7 + 63) / 64 * 8 + 8;
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+            if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
+        } else {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_sg_mask(c->stream, fused_bl, c->max_len, pv0, rv0, sp0, mp));
+            if ((rc = t.end(fused_bl ? "k_sg_mask<baseline>" : "k_sg_mask"))) return rc;
+        }
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_scan(c->stream, c->rec_nhits.as<int32_t>(), R, c->scan_blocks.as<int64_t>(),
+                                      c->rec_out_start.as<int64_t>()));
+            if ((rc = t.end("k_scan(hit counts)"))) return rc;
+        }
+        int64_t total = 0;
+        WFA_HIP_CHECK(hipMemcpyAsync(&total, c->scan_blocks.as<int64_t>() + nb, sizeof(int64_t),
+                                     hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if ((rc = c->hit_out.ensure((size_t)total * 60))) return rc;
+        if ((rc = c->hit_desc.ensure((size_t)total * sizeof(int4)))) return rc;
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_hit_runs(c->stream, rv0, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
+                                          c->rec_out_start.as<int64_t>(), c->hit_desc.as<int4>()));
+            if ((rc = t.end("k_hit_runs"))) return rc;
+        }
+        {
+            RowParams rp{le, re, max_len};
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_hit_rows(c->stream, pv0, rv0, sp0, rp, c->hit_desc.as<int4>(), total,
+                                          c->hit_out.as<uint8_t>()));
+            if ((rc = t.end("k_hit_rows"))) return rc;
+        }
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->n_hits = total;
+        *n_hits = total;
+        return WFA_OK;
+    }
+
     HitParams hp{};
     hp.le = le; hp.re = re; hp.max_len = max_len;
     hp.bl_start = bl_start; hp.bl_end = bl_end;
-    hp.bm_words = (c->max_len + 63) / 64 + 1;
+    hp.bm_words = (c->max_len + 7 + 63) / 64 + 9;  // bits are indexed from the 16-byte aligned base
     hp.chunk_rows = 256;
+    hp.use_fast = getenv("WFA_DISABLE_FAST") ? 0 : 1;
     const int64_t waves = hits_waves(R);
     int64_t want_rows = waves * hp.chunk_rows + c->pool_n / 256 + 4096;
     if (c->hit_tmp_rows < want_rows) {
@@ -259,7 +326,8 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     if (c->comm) (void)wfa_rccl_destroy(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
-                      &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->sg.tab,
+                      &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
+                      &c->hit_desc, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
@@ -330,7 +398,29 @@ int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int3
             return fail(WFA_E_INVALID, "bad polarity code %d at record %lld", (int)pol[r], (long long)r);
         if (len[r] > max_len) max_len = len[r];
     }
+    // per-record region of the hit bitmap: bits indexed from the 16-byte aligned chunk base,
+    // whole 64-bit words, one spare word
+    std::vector<int64_t> bm_off((size_t)R);
+    int64_t bm_total = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        bm_off[(size_t)r] = bm_total;
+        bm_total += ((int64_t)len[r] + 7 + 63) / 64 * 8 + 8;
+    }
+    c->bitmap_bytes = bm_total + 64;
+    c->bitmap_clean = false;
+    // span mode: every record the same length (multiple of 8, >= 24), laid out back to back from a
+    // 16-byte aligned start, one polarity class
+    c->span_ok = R > 0 && len[0] >= 24 && (len[0] % 8) == 0 && (off[0] % 8) == 0;
+    for (int64_t r = 0; c->span_ok && r < R; ++r)
+        c->span_ok = len[r] == len[0] && off[r] == off[0] + r * (int64_t)len[0] &&
+                     (pol[r] == WFA_POL_POSITIVE) == (pol[0] == WFA_POL_POSITIVE);
+    if (c->span_ok) {
+        c->span_L = len[0];
+        c->span_off0 = off[0];
+        c->span_positive = pol[0] == WFA_POL_POSITIVE;
+    }
     const size_t n = (size_t)R;
+    if ((rc = h2d(c, c->bm_off, bm_off.data(), n * 8))) return rc;
     if ((rc = h2d(c, c->off, off, n * 8))) return rc;
     if ((rc = h2d(c, c->len, len, n * 4))) return rc;
     if ((rc = h2d(c, c->baseline, baseline, n * 8))) return rc;

@@ -74,7 +74,14 @@ struct wfa_ctx {
     int64_t R = 0;
     int32_t max_len = 0;
     bool have_records = false;
-    wfa::DevBuf off, len, baseline, pol, thr, ts, dt, board, chan, rid, fixed_bl;
+    wfa::DevBuf off, len, baseline, pol, thr, ts, dt, board, chan, rid, fixed_bl, bm_off;
+    int64_t bitmap_bytes = 0;  // mask bits of all records (k_sg_mask -> k_hit_runs)
+    // span mode eligibility (uniform length, contiguous, aligned; see SpanParams)
+    bool span_ok = false;
+    int32_t span_L = 0;
+    int64_t span_off0 = 0;
+    int span_positive = 0;
+    bool bitmap_clean = false;  // padding bytes of the bitmap are zero
 
     wfa::SgPlanDev sg;
     bool have_sg = false;
@@ -88,6 +95,8 @@ struct wfa_ctx {
     wfa::DevBuf rec_out_start;  // int64 per record
     wfa::DevBuf scan_blocks;    // int64 per scan block
     wfa::DevBuf hit_out;        // final rows
+    wfa::DevBuf bitmap;         // 1 bit per sample, per-record regions (bm_off)
+    wfa::DevBuf hit_desc;       // int4 (record, start, end, k) per hit
     int64_t n_hits = -1;
 
     wfa::DevBuf out_rows;  // per-record feature rows

@@ -382,6 +382,719 @@ __global__ __launch_bounds__(kBlock) void k_hits(PoolView pool, RecView rec, SgP
     }
 }
 
+
+// =============================================================================================
+// K7 fast path: fused baseline + Savitzky-Golay + threshold hits in exact integer arithmetic
+// =============================================================================================
+// For uint16 samples the SG output is the exact rational  y = (n . x) / den  with integer n
+// (sg_plan.py).  The reference thresholds  sig = +-(b - f32(y)) >= thr ; float32 rounding and the
+// float64 subtraction are monotone, so the mask is  Z <= Zc  for an integer Zc, up to a band of
+// `margin` numerator units that covers the float32 rounding of y.
+//
+// The pass is split so that the HBM-streaming part stays lean (no LDS, few registers):
+//   A  k_sg_mask   one wave per record: 16-byte loads (next record's tiles already in flight),
+//                  halo dwords over DPP wave shifts, 8 outputs x (H+1) v_dot2_i32_i16 per lane,
+//                  one v_cmp per sample against the candidate bound.  Candidates inside the band
+//                  ("borderline", rare) and the 2H edge samples are decided with the reference's
+//                  float64 code.  Writes 1 mask bit per sample + the run count per record.
+//      scan        exclusive scan of the run counts = row offsets in (record, start) order.
+//   B1 k_hit_runs  one lane per record: bit scan of its mask words -> (record, start, end) rows.
+//   B2 k_hit_rows  one lane per hit: re-reads the hit window (L2 / Infinity-Cache resident),
+//                  y = f32((n . x)/den) exactly as above (float64 chain below the guard),
+//                  float64 signal, first-argmax, integral, and the packed 60-byte row.
+
+typedef short wfa_s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int sdot2_acc(uint32_t pair, uint32_t coef, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(wfa_s2, pair), __builtin_bit_cast(wfa_s2, coef), acc, false);
+}
+__device__ __forceinline__ uint32_t dpp_from_prev_lane(uint32_t lane0_value, uint32_t v) {
+    // lane i <- lane i-1 ; lane 0 keeps lane0_value (wave_shr:1, bound_ctrl off)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_from_next_lane(uint32_t lane63_value, uint32_t v) {
+    // lane i <- lane i+1 ; lane 63 keeps lane63_value (wave_shl:1)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane63_value, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+// Sum over the wave with DPP row shifts / broadcasts only (no LDS crossbar); result is wave-uniform.
+__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8  -> lane 15 of each row = row sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int clamp_to_i32(double v) {
+    return v >= 2147483647.0 ? INT32_MAX : (v <= -2147483648.0 ? INT32_MIN : (int)v);
+}
+
+struct Tile {
+    uint32_t d[4];
+};
+
+__device__ __forceinline__ Tile load_tile(const uint16_t* __restrict__ pool, int64_t a0, int t, int lane,
+                                          int64_t rec_lo, int64_t rec_hi, uint32_t fill) {
+    // aligned 16-byte chunk [c, c+8) samples; loaded only if it overlaps the record
+    const int64_t c = a0 + (int64_t)t * 512 + lane * 8;
+    Tile r;
+    if (c + 8 > rec_lo && c < rec_hi) {
+        const uint4 v = *reinterpret_cast<const uint4*>(pool + c);
+        r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+    } else {
+        r.d[0] = r.d[1] = r.d[2] = r.d[3] = fill;
+    }
+    return r;
+}
+
+struct RecP {  // wave-uniform record parameters (scalar loads)
+    int64_t off;
+    int L;
+    int pol;
+    double thr;
+    double bl;
+};
+__device__ __forceinline__ RecP load_recp(const RecView& rec, int64_t r, bool want_bl) {
+    RecP p;
+    p.off = rec.off[r];
+    p.L = rec.len[r];
+    p.pol = rec.pol[r];
+    p.thr = rec.thr[r];
+    p.bl = want_bl ? rec.baseline[r] : 0.0;
+    return p;
+}
+
+// integer candidate band:  candidate <=> Z < zhi ; certainly masked <=> Z <= zlo
+__device__ __forceinline__ void int_band(bool positive, double b, double thr, double den, double shift,
+                                         int margin, int& zhi, int& zlo) {
+    // negative/unknown: mask <=> y <= b - thr ; positive: mask <=> -y <= -(b + thr)
+    const double tq = positive ? -(b + thr) * den : (b - thr) * den;
+    if (!(tq == tq)) { zhi = INT32_MIN; zlo = INT32_MIN; return; }  // NaN: no hits
+    const double tz = floor(tq) + shift;
+    zhi = clamp_to_i32(tz + (double)margin + 1.0);
+    zlo = clamp_to_i32(tz - (double)margin);
+}
+
+// 8 SG numerators of one lane's chunk from its own dwords and the halo dwords of both neighbours.
+//   E[0..3] = previous chunk, E[4..7] = own, E[8..11] = next  (samples biased by -32768)
+template <int W>
+__device__ __forceinline__ void sg_chunk_numerators(const uint32_t (&E)[12], const uint32_t* cpm, int (&Z)[8]) {
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    uint32_t S[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) S[k] = __builtin_amdgcn_alignbit(E[k + 1], E[k], 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ws = j - H;  // first sample of the window, relative to the chunk
+        int acc = 0;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const uint32_t pair = (ws & 1) == 0 ? E[ws / 2 + m + 4] : S[(ws - 1) / 2 + m + 4];
+            acc = sdot2_acc(pair, cpm[m], acc);
+        }
+        Z[j] = acc;
+    }
+}
+
+// PF = tiles of the next record kept in flight per wave (PF x 1 KiB)
+template <int W, bool FUSED_BASELINE, int PF>
+__global__ __launch_bounds__(kBlock) void k_sg_mask(PoolView pool, RecView rec, SgParams sg, MaskParams mp) {
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    static_assert(W % 2 == 1 && W >= 3 && W <= 15, "fast path needs the halo inside the adjacent lane");
+    const int lane = lane_id();
+    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block());
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+
+    // coefficient pairs (n[2m], n[2m+1]) as packed int16
+    uint32_t cp_pos[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        const int n0 = sg.itab[2 * m];
+        const int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
+        cp_pos[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+    }
+    const double bias = 32768.0 * (double)sg.den;  // sum(n) == den for a smoothing filter
+    const double dden = (double)sg.den, dden_e = (double)sg.den_edge;
+    const int margin = sg.margin, margin_e = sg.margin_edge;
+
+    // integer rows of the edge projection (2H rows x W), one row per edge lane
+    __shared__ int32_t etab[2 * H * W];
+    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
+    __syncthreads();
+    int erow[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) erow[k] = lane < 2 * H ? etab[lane * W + k] : 0;
+
+    RecP cp{};
+    Tile pf[PF];
+    if (wave0 < rec.R) {
+        cp = load_recp(rec, wave0, !FUSED_BASELINE);
+        const int sh0 = (int)(cp.off & 7);
+        const uint32_t fill0 = cp.pol == WFA_POL_POSITIVE ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < PF; ++t)
+            pf[t] = load_tile(pool.u16, cp.off - sh0, t, lane, cp.off, cp.off + cp.L, fill0);
+    }
+
+    for (int64_t r = wave0; r < rec.R; r += nwaves) {
+        const int64_t rn = r + nwaves;
+        const bool has_next = rn < rec.R;
+        RecP np{};
+        if (has_next) np = load_recp(rec, rn, !FUSED_BASELINE);
+
+        const int L = cp.L;
+        const int64_t off = cp.off;
+        const bool positive = cp.pol == WFA_POL_POSITIVE;
+        const int sh = (int)(off & 7);  // bit index of sample i in the record's mask = i + sh
+        const int nbits = L + sh;
+        const int nw = (nbits + kWave - 1) / kWave;
+        const int T = (nbits + 511) / 512;
+        const uint32_t fill_raw = positive ? 0u : 0xffffffffu;  // out-of-record samples: never candidates
+        const int64_t a0 = off - sh;
+        uint8_t* __restrict__ bm8 = mp.bitmap + rec.bm_off[r];
+
+        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, off, L);
+        double baseline;
+        if (FUSED_BASELINE) {
+            const int e = mp.bl_end < L ? mp.bl_end : L;
+            int s = 0;
+            for (int i = mp.bl_start + lane; i < e; i += kWave) s += src.xu[i];
+            const int tot = wave_sum_i32_dpp(s);  // <= 32760 * 65535 < 2^31
+            baseline = (e <= mp.bl_start) ? __longlong_as_double(0x7ff8000000000000LL)
+                                          : (double)tot / (double)(e - mp.bl_start);
+            if (lane == 0) rec.baseline_rw[r] = baseline;
+        } else {
+            baseline = cp.bl;
+        }
+        const double thr = cp.thr;
+        auto exact_mask = [&](int i) {  // the reference's float64 decision for sample i
+            const double w = src.at(i);
+            const double sig = positive ? (w - baseline) : (baseline - w);
+            return sig >= thr;
+        };
+
+        int n_runs = 0;
+        if (src.sg.w == W) {
+            // ---- edges first (their bits are merged into the lane bytes below) ----------------------
+            uint64_t emask = 0;
+            {
+                bool m = false;
+                if (lane < 2 * H) {
+                    // integer projection row . first/last W samples (independent loads, one latency)
+                    const uint16_t* xe = lane < H ? src.xu : src.xu + (L - W);
+                    int xv[W];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) xv[k] = xe[k];
+                    int acc = 0;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) acc += erow[k] * xv[k];
+                    int zhi_e, zlo_e;
+                    int_band(positive, baseline, thr, dden_e, 0.0, margin_e, zhi_e, zlo_e);
+                    const int ze = positive ? -acc : acc;
+                    m = ze < zhi_e;
+                    if (m && ze > zlo_e) m = exact_mask(lane < H ? lane : L - 2 * H + lane);  // borderline
+                }
+                emask = __ballot(m);
+            }
+            int zhi, zlo;
+            int_band(positive, baseline, thr, dden, positive ? bias : -bias, margin, zhi, zlo);
+            uint32_t cpm[NP];
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                // negated coefficients for positive polarity: Z = -(n.x - bias)
+                const uint32_t lo = (0u - (cp_pos[m] & 0xffffu)) & 0xffffu, hi = (0u - (cp_pos[m] >> 16)) << 16;
+                cpm[m] = positive ? (lo | hi) : cp_pos[m];
+            }
+            const uint32_t fillb = fill_raw ^ 0x80008000u;
+            uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;  // biased dwords of "lane -1"
+            uint32_t carry_bit = 0;                                    // mask bit of the sample before the tile
+            Tile fillt; fillt.d[0] = fillt.d[1] = fillt.d[2] = fillt.d[3] = fill_raw;
+            auto mem_tile = [&](int t) { return load_tile(pool.u16, a0, t, lane, off, off + L, fill_raw); };
+            auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
+                uint32_t E[12];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) E[4 + k] = cur.d[k] ^ 0x80008000u;
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80008000u;
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80008000u;
+                const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80008000u;
+                const uint32_t n3 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[3], 0) ^ 0x80008000u;
+                E[0] = dpp_from_prev_lane(p0, E[4]);
+                E[1] = dpp_from_prev_lane(p1, E[5]);
+                E[2] = dpp_from_prev_lane(p2, E[6]);
+                E[3] = dpp_from_prev_lane(p3, E[7]);
+                E[8] = dpp_from_next_lane(n0, E[4]);
+                E[9] = dpp_from_next_lane(n1, E[5]);
+                E[10] = dpp_from_next_lane(n2, E[6]);
+                E[11] = dpp_from_next_lane(n3, E[7]);
+                int Z[8];
+                sg_chunk_numerators<W>(E, cpm, Z);
+                bool cand = false;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cand |= Z[j] < zhi;
+                uint32_t byte = 0;
+                const bool tile_has_edge = emask != 0;  // rare
+                if (__ballot(cand) != 0 || tile_has_edge) {
+                    const int ib = t * 512 + lane * 8 - sh;  // record index of this lane's sample 0
+                    uint32_t border = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in = (ib + j >= H) && (ib + j < L - H);
+                        const bool c = in && (Z[j] < zhi);
+                        byte |= (uint32_t)c << j;
+                        border |= (uint32_t)(c && Z[j] > zlo) << j;
+                    }
+                    if (__ballot(border != 0) != 0) {
+                        while (border) {  // rare: the reference's float64 arithmetic decides
+                            const int j = __ffs((int)border) - 1;
+                            border &= border - 1;
+                            if (!exact_mask(ib + j)) byte &= ~(1u << j);
+                        }
+                    }
+                    if (tile_has_edge) {
+                        uint64_t em = emask;
+                        while (em) {
+                            const int e = __ffsll((long long)em) - 1;
+                            em &= em - 1;
+                            const int a = (e < H ? e : L - 2 * H + e) + sh;
+                            if ((a >> 9) == t && ((a >> 3) & 63) == lane) byte |= 1u << (a & 7);
+                        }
+                    }
+                    if (__ballot(byte != 0) != 0) {
+                        const uint32_t prevb = dpp_from_prev_lane(carry_bit << 7, byte);
+                        const uint32_t starts = byte & ~((byte << 1) | (prevb >> 7)) & 0xffu;
+                        n_runs += __popc(starts);
+                    }
+                }
+                if (t * 64 + lane < nw * 8) bm8[t * 64 + lane] = (uint8_t)byte;
+                carry_bit = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
+                p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
+                p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
+                p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
+                p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
+            };
+            Tile tail = fillt;  // tile PF when the record is longer than the prefetch
+            if (T > PF) tail = mem_tile(PF);
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                if (t < T) {
+                    if (t + 1 < PF) do_tile(t, pf[t], t + 1 < T ? pf[t + 1 < PF ? t + 1 : 0] : fillt);
+                    else do_tile(t, pf[t], t + 1 < T ? tail : fillt);
+                }
+            }
+            for (int t = PF; t < T; ++t) {
+                const Tile cur = tail;
+                tail = t + 1 < T ? mem_tile(t + 1) : fillt;
+                do_tile(t, cur, tail);
+            }
+            if (__ballot(n_runs != 0) != 0) n_runs = wave_sum_i32_dpp(n_runs);
+        } else {
+            // literal phase A (records shorter than the window): one sample per lane
+            uint64_t prev_msb = 0;
+            for (int wi = 0; wi < nw; ++wi) {
+                const int i = wi * kWave + lane - sh;  // bit wi*64+lane <-> sample i
+                const bool m = (i >= 0 && i < L) ? exact_mask(i) : false;
+                const uint64_t word = __ballot(m);
+                if (lane < 8) bm8[wi * 8 + lane] = (uint8_t)(word >> (8 * lane));
+                n_runs += __popcll(word & ~((word << 1) | prev_msb));
+                prev_msb = word >> 63;
+            }
+        }
+        if (lane == 0) mp.rec_nhits[r] = n_runs;
+
+        // ---- next record: parameters are here, request its first tiles -------------------------------
+        if (has_next) {
+            const int shn = (int)(np.off & 7);
+            const uint32_t filln = np.pol == WFA_POL_POSITIVE ? 0u : 0xffffffffu;
+#pragma unroll
+            for (int t = 0; t < PF; ++t)
+                pf[t] = load_tile(pool.u16, np.off - shn, t, lane, np.off, np.off + np.L, filln);
+        }
+        cp = np;
+    }
+}
+
+// ---- A (span mode): uniform-length, contiguous, 16-byte aligned records ----------------------------
+// A wave owns a span of up to 64 consecutive records and treats their samples as one stream of
+// 512-sample tiles, so every lane does useful work in every tile.  The per-record work (baseline,
+// integer bands, the 2H edge samples) is done first with one lane per record; the results sit in
+// an LDS table that the tile loop indexes with the lane's record number.
+struct SpanTable {  // per wave, in LDS
+    int zhi[kWave], zlo[kWave], eb[kWave], nr[kWave];
+    double bl[kWave], thr[kWave];
+};
+
+// phase 0: lane = record of the span.  Kept out of line so its registers do not add to the tile loop's.
+template <int W, bool FUSED_BASELINE>
+__device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, const RecView& rec, const SgParams& sg,
+                                                      const MaskParams& mp, const int32_t* __restrict__ etab,
+                                                      int64_t g_base, int64_t r0, int nrec, int L, bool positive,
+                                                      SpanTable* __restrict__ tab) {
+    constexpr int H = W / 2;
+    const int lane = lane_id();
+    const int64_t r = r0 + lane;
+    int zhi = INT32_MIN, zlo = INT32_MIN, eb = 0;
+    double baseline = 0.0, thr = 0.0;
+    if (lane < nrec) {
+        const double bias = 32768.0 * (double)sg.den;
+        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * L) >> 3);
+        thr = rec.thr[r];
+        if (FUSED_BASELINE) {
+            const int s0 = mp.bl_start, e0 = mp.bl_end < L ? mp.bl_end : L;
+            int tot = 0;
+            for (int c = s0 >> 3; c * 8 < e0; c += 4) {  // 4 independent 16-byte loads per round
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((c + k) * 8 < e0) ? p[c + k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int idx = (c + k) * 8 + j;
+                        const int x = (int)((d[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                        tot += (idx >= s0 && idx < e0) ? x : 0;
+                    }
+                }
+            }
+            baseline = (e0 <= s0) ? __longlong_as_double(0x7ff8000000000000LL) : (double)tot / (double)(e0 - s0);
+            rec.baseline_rw[r] = baseline;
+        } else {
+            baseline = rec.baseline[r];
+        }
+        int_band(positive, baseline, thr, (double)sg.den, positive ? bias : -bias, sg.margin, zhi, zlo);
+
+        // edges: integer projection rows (LDS, broadcast reads) on the first / last W samples
+        int zhi_e, zlo_e;
+        int_band(positive, baseline, thr, (double)sg.den_edge, 0.0, sg.margin_edge, zhi_e, zlo_e);
+        const uint4 a0 = p[0], a1 = p[1], b0 = p[(L >> 3) - 2], b1 = p[(L >> 3) - 1];
+        const uint32_t da[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const uint32_t db[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        int xl[W], xr[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            xl[k] = (int)((da[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+            const int q = 16 - W + k;  // last W of the last 16 samples
+            xr[k] = (int)((db[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+        }
+        uint32_t border_e = 0;
+        for (int e = 0; e < 2 * H; ++e) {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc += etab[e * W + k] * (e < H ? xl[k] : xr[k]);
+            const int ze = positive ? -acc : acc;
+            const bool m = ze < zhi_e;
+            eb |= (int)m << e;
+            border_e |= (uint32_t)(m && ze > zlo_e) << e;
+        }
+        if (border_e) {  // rare: float64 reference code decides
+            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * L, L);
+            while (border_e) {
+                const int e = __ffs((int)border_e) - 1;
+                border_e &= border_e - 1;
+                const double w = src.at(e < H ? e : L - 2 * H + e);
+                const double sig = positive ? (w - baseline) : (baseline - w);
+                if (!(sig >= thr)) eb &= ~(1 << e);
+            }
+        }
+    }
+    tab->zhi[lane] = zhi; tab->zlo[lane] = zlo; tab->eb[lane] = eb; tab->nr[lane] = 0;
+    tab->bl[lane] = baseline; tab->thr[lane] = thr;
+}
+
+template <int W, bool FUSED_BASELINE>
+__global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView rec, SgParams sg,
+                                                         MaskParams mp, SpanParams sp) {
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    static_assert(W % 2 == 1 && W >= 3 && W <= 15, "halo must fit in the adjacent lane");
+    __shared__ SpanTable s_tab[kWavesPerBlock];
+    __shared__ int32_t etab[2 * H * W];
+    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
+    __syncthreads();
+    const int lane = lane_id();
+    const int wv = wave_in_block();
+    SpanTable* tab = &s_tab[wv];
+    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int L = sp.L;
+    const bool positive = sp.positive != 0;
+
+    uint32_t cpm[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        int n0 = sg.itab[2 * m];
+        int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
+        if (positive) { n0 = -n0; n1 = -n1; }  // Z = -(n.x - bias)
+        cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+    }
+    const uint32_t fill_raw = positive ? 0u : 0xffffffffu;
+    const uint32_t fillb = fill_raw ^ 0x80008000u;
+    const uint4* __restrict__ pool16 = reinterpret_cast<const uint4*>(pool.u16);
+
+    for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
+        const int64_t r0 = span * sp.rs;
+        const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
+        const int64_t g_base = sp.off0 + r0 * L;  // pool index of the span's first sample (multiple of 8)
+
+        span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive, tab);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        // ================= phase 1: tiles over the span's sample stream =================
+        const int span_samples = nrec * L;
+        const int T = (span_samples + 511) / 512;
+        auto tile_at = [&](int t) {
+            Tile x;
+            const int pos = t * 512 + lane * 8;
+            if (t < T && pos < span_samples) {
+                const uint4 v = pool16[((g_base + pos) >> 3)];
+                x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
+            } else {
+                x.d[0] = x.d[1] = x.d[2] = x.d[3] = fill_raw;
+            }
+            return x;
+        };
+        int rl = (lane * 8) / L;        // record (within the span) of this lane's chunk
+        int i0 = lane * 8 - rl * L;     // position of the chunk inside its record (multiple of 8)
+        uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;
+        uint32_t carry_msb = 0;
+        Tile cur = tile_at(0), nxt = tile_at(1), nn = tile_at(2);
+        for (int t = 0; t < T; ++t) {
+            const Tile fut = tile_at(t + 3);
+            const bool in_span = t * 512 + lane * 8 < span_samples;
+            const int rli = in_span ? rl : 0;
+            const int zhi = in_span ? tab->zhi[rli] : INT32_MIN;
+
+            uint32_t E[12];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) E[4 + k] = cur.d[k] ^ 0x80008000u;
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80008000u;
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80008000u;
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80008000u;
+            const uint32_t n3 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[3], 0) ^ 0x80008000u;
+            E[0] = dpp_from_prev_lane(p0, E[4]);
+            E[1] = dpp_from_prev_lane(p1, E[5]);
+            E[2] = dpp_from_prev_lane(p2, E[6]);
+            E[3] = dpp_from_prev_lane(p3, E[7]);
+            E[8] = dpp_from_next_lane(n0, E[4]);
+            E[9] = dpp_from_next_lane(n1, E[5]);
+            E[10] = dpp_from_next_lane(n2, E[6]);
+            E[11] = dpp_from_next_lane(n3, E[7]);
+            int Z[8];
+            sg_chunk_numerators<W>(E, cpm, Z);
+
+            // interior outputs of this chunk: all 8, except next to a record boundary
+            const bool first = i0 == 0, last = i0 == L - 8;
+            const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
+            bool cand = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cand |= Z[j] < zhi;
+            const int ebr = (in_span && (first || last)) ? tab->eb[rli] : 0;
+            const uint32_t ebits = first ? ((uint32_t)ebr & ((1u << H) - 1u))
+                                         : (last ? (((uint32_t)ebr >> H) << (8 - H)) & 0xffu : 0u);
+            uint32_t byte = 0;
+            if (__ballot(cand || ebits != 0) != 0) {
+                const int zlo = tab->zlo[rli];
+                uint32_t border = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool c = Z[j] < zhi;
+                    byte |= (uint32_t)c << j;
+                    border |= (uint32_t)(c && Z[j] > zlo) << j;
+                }
+                byte &= vb;
+                border &= vb;
+                if (__ballot(border != 0) != 0) {
+                    if (border) {  // rare: the reference's float64 arithmetic decides
+                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
+                        const double baseline = tab->bl[rli], thr = tab->thr[rli];
+                        while (border) {
+                            const int j = __ffs((int)border) - 1;
+                            border &= border - 1;
+                            const double w = src.at(i0 + j);
+                            const double sig = positive ? (w - baseline) : (baseline - w);
+                            if (!(sig >= thr)) byte &= ~(1u << j);
+                        }
+                    }
+                }
+                byte |= ebits;
+                if (__ballot(byte != 0) != 0) {
+                    // run starts: a set bit whose predecessor (same record) is clear
+                    uint32_t prevb = dpp_from_prev_lane(carry_msb << 7, byte);
+                    if (first) prevb = 0;
+                    const uint32_t starts = byte & ~((byte << 1) | (prevb >> 7)) & 0xffu;
+                    if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
+                }
+            }
+            if (in_span) mp.bitmap[sp.bm_off0 + (r0 + rl) * sp.bm_stride + (i0 >> 3)] = (uint8_t)byte;
+            carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
+            p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
+            p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
+            p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
+            p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
+            cur = nxt; nxt = nn; nn = fut;
+            i0 += 512;
+            while (i0 >= L) { i0 -= L; ++rl; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < nrec) mp.rec_nhits[r0 + lane] = tab->nr[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ---- B1: runs of set bits of every record -> hit descriptors ----------------------------------------
+__global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t* __restrict__ bitmap,
+                                                     const int32_t* __restrict__ nhits,
+                                                     const int64_t* __restrict__ out_start,
+                                                     int4* __restrict__ desc) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rec.R) return;
+    const int n = nhits[r];
+    if (n == 0) return;
+    const int sh = (int)(rec.off[r] & 7);
+    const int nbits = rec.len[r] + sh;
+    const int nw = (nbits + 63) / 64;
+    const uint64_t* __restrict__ bm = reinterpret_cast<const uint64_t*>(bitmap + rec.bm_off[r]);
+    int4* __restrict__ out = desc + out_start[r];
+    int k = 0;
+    int run_start = -1;  // >= 0 while inside a run
+    for (int wi = 0; wi < nw && k < n; ++wi) {
+        const uint64_t w = bm[wi];
+        int pos = 0;  // bits below pos are consumed
+        while (pos < 64) {
+            const uint64_t rest = (run_start < 0 ? w : ~w) & (~0ull << pos);
+            if (rest == 0) break;
+            const int b = __ffsll((long long)rest) - 1;
+            if (run_start < 0) {
+                run_start = wi * 64 + b;
+            } else {
+                out[k] = make_int4((int)r, run_start - sh, wi * 64 + b - sh, 0);
+                ++k;
+                run_start = -1;
+            }
+            pos = b + 1;
+        }
+    }
+    if (run_start >= 0 && k < n) out[k] = make_int4((int)r, run_start - sh, nw * 64 - sh, 0);
+}
+
+// ---- B2: one lane per hit -------------------------------------------------------------------------------
+struct HitAcc {
+    double best;
+    int best_i;
+    double sum;
+    __device__ __forceinline__ void add(double s, int i) {
+        if (s > best) { best = s; best_i = i; }  // ascending i: first maximum kept (np.argmax)
+        sum += s > 0.0 ? s : 0.0;                 // hit_finder.py:380
+    }
+};
+
+template <int SRC, int W>
+__global__ __launch_bounds__(kBlock) void k_hit_rows(PoolView pool, RecView rec, SgParams sg, RowParams rp,
+                                                     const int4* __restrict__ desc, int64_t n_hits,
+                                                     uint8_t* __restrict__ out) {
+    const int64_t h = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (h >= n_hits) return;
+    const int4 d = desc[h];
+    const int64_t r = d.x;
+    const int start = d.y, end = d.z;
+    const int L = rec.len[r];
+    const int64_t off = rec.off[r];
+    WaveSrc<SRC> src = make_src<SRC>(pool, sg, off, L);
+    HitCtx hc;
+    hc.L = L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
+    hc.thr = rec.thr[r];
+    hc.positive = rec.pol[r] == WFA_POL_POSITIVE;
+    hc.baseline = rec.baseline[r];
+    const int seg_start = start - hc.le > 0 ? start - hc.le : 0;
+    const int seg_end = end + hc.re < hc.max_len ? end + hc.re : hc.max_len;
+
+    HitAcc acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
+    constexpr int H = W / 2;
+    bool done = false;
+    if (SRC == WFA_SRC_SG_FUSED && W > 0) {
+        if (src.sg.w == W && sg.int_ok && seg_start >= H && seg_end <= L - H) {
+            // interior window: integer numerators from aligned 16-byte chunks (3-chunk rolling window)
+            constexpr int NP = (W > 0 ? W : 1) / 2 + 1;
+            uint32_t cpm[NP];
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                const int n0 = sg.itab[2 * m];
+                const int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
+                cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+            }
+            const int bias_i = 32768 * sg.den;
+            const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
+            const int64_t g0 = off + seg_start, g1 = off + seg_end;  // pool indices
+            int64_t c = g0 >> 3;
+            const int64_t c_last = (g1 - 1) >> 3;
+            const uint4* __restrict__ p16 = reinterpret_cast<const uint4*>(pool.u16);
+            const uint4 zero4 = make_uint4(0, 0, 0, 0);
+            uint4 prev = c > 0 ? p16[c - 1] : zero4;
+            uint4 cur = p16[c];
+            for (; c <= c_last; ++c) {
+                const uint4 nxt = p16[c + 1];  // pool allocation has 256 B of slack
+                uint32_t E[12] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w,
+                                  nxt.x, nxt.y, nxt.z, nxt.w};
+#pragma unroll
+                for (int k = 0; k < 12; ++k) E[k] ^= 0x80008000u;
+                int Z[8];
+                sg_chunk_numerators<(W > 0 ? W : 3)>(E, cpm, Z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t g = c * 8 + j;
+                    if (g >= g0 && g < g1) {
+                        const int i = (int)(g - off);
+                        const int y_num = Z[j] + bias_i;
+                        float y32;
+                        if (y_num >= guard) y32 = (float)((double)y_num * sg.rden);
+                        else y32 = sg_value_f64(src.xu, L, i, src.sg);
+                        const double sgn = hc.positive ? ((double)y32 - hc.baseline) : (hc.baseline - (double)y32);
+                        acc.add(sgn, i);
+                    }
+                }
+                prev = cur;
+                cur = nxt;
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+        for (int i = seg_start; i < seg_end; ++i) acc.add(hit_signal<SRC>(src, hc, i), i);
+    }
+
+    const int dt_ns = rec.dt[r];
+    const double sip = (double)dt_ns * 1e3;  // hit_finder.py:382
+    const int pos = acc.best_i;
+    const int64_t rise = (int64_t)(pos - start > 0 ? pos - start : 0) * dt_ns;
+    const int64_t fall = (int64_t)((end - 1) - pos > 0 ? (end - 1) - pos : 0) * dt_ns;
+    const int64_t gts = (int64_t)((double)rec.ts[r] + (double)pos * sip);  // :383-386
+    const int rl = L > 0 ? L : 0;
+    int es = seg_start < rl ? seg_start : rl;
+    int ee = seg_end < rl ? seg_end : rl;
+    if (ee < es) ee = es;
+    uint32_t* row = reinterpret_cast<uint32_t*>(out + h * 60);
+    put_i64(row, 0, (int64_t)pos);
+    put_f32(row, 2, (float)acc.best);
+    put_f32(row, 3, (float)acc.sum);
+    row[4] = (uint32_t)es;
+    row[5] = (uint32_t)ee;
+    put_f32(row, 6, (float)(double)(ee - es));
+    row[7] = (uint32_t)dt_ns;
+    put_f32(row, 8, (float)(double)rise);
+    put_f32(row, 9, (float)(double)fall);
+    put_i64(row, 10, gts);
+    row[12] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
+    put_i64(row, 13, rec.rid[r]);
+}
+
 // ---- exclusive scan of per-record hit counts (int32 -> int64 offsets) --------------------------
 constexpr int kScanTile = 1024;  // records per scan block (256 threads x 4)
 
@@ -670,7 +1383,10 @@ hipError_t launch_hits(hipStream_t st, int source, bool fused_baseline, const Po
     } else if (source == WFA_SRC_F32) {
         WFA_LAUNCH_HITS(WFA_SRC_F32, false);
     } else {
-        if (fused_baseline) WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, true); else WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, false);
+        const bool done = false;
+        if (!done) {
+            if (fused_baseline) WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, true); else WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, false);
+        }
     }
 #undef WFA_LAUNCH_HITS
     return hipGetLastError();
@@ -717,6 +1433,88 @@ hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& poo
         hipLaunchKernelGGL((k_width_integral<WFA_SRC_F32>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, wp, out);
     else
         hipLaunchKernelGGL((k_width_integral<WFA_SRC_SG_FUSED>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, wp, out);
+    return hipGetLastError();
+}
+
+bool sg_mask_supported(const SgParams& sg) {
+    return sg.int_ok && sg.W >= 5 && sg.W <= 15 && (sg.W & 1);
+}
+
+hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
+                          const RecView& rec, const SgParams& sg, const MaskParams& mp) {
+    const int grid = grid_for_records(rec.R);
+    const bool pf2 = (max_len + 7 + 511) / 512 <= 2;
+#define WFA_MASK2(WW, FB, PFN) \
+    hipLaunchKernelGGL((k_sg_mask<WW, FB, PFN>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp)
+#define WFA_MASK(WW)                                                                            \
+    case WW:                                                                                    \
+        if (fused_baseline) { if (pf2) WFA_MASK2(WW, true, 2); else WFA_MASK2(WW, true, 4); }  \
+        else { if (pf2) WFA_MASK2(WW, false, 2); else WFA_MASK2(WW, false, 4); }               \
+        break;
+    switch (sg.W) {
+        WFA_MASK(5)
+        WFA_MASK(7)
+        WFA_MASK(9)
+        WFA_MASK(11)
+        WFA_MASK(13)
+        WFA_MASK(15)
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_MASK
+#undef WFA_MASK2
+    return hipGetLastError();
+}
+
+hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
+                               const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
+    int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    const int grid = (int)g;
+#define WFA_SPAN(WW)                                                                                              \
+    case WW:                                                                                                      \
+        if (fused_baseline)                                                                                       \
+            hipLaunchKernelGGL((k_sg_mask_span<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp);  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_sg_mask_span<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp); \
+        break;
+    switch (sg.W) {
+        WFA_SPAN(5)
+        WFA_SPAN(7)
+        WFA_SPAN(9)
+        WFA_SPAN(11)
+        WFA_SPAN(13)
+        WFA_SPAN(15)
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_SPAN
+    return hipGetLastError();
+}
+
+hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
+                           const int64_t* out_start, int4* desc) {
+    if (rec.R == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((rec.R + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kBlock), 0, st, rec, bitmap, nhits, out_start, desc);
+    return hipGetLastError();
+}
+
+hipError_t launch_hit_rows(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
+                           const RowParams& rp, const int4* desc, int64_t n_hits, uint8_t* out) {
+    if (n_hits == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_hits + kBlock - 1) / kBlock);
+#define WFA_ROWS(WW) \
+    case WW: hipLaunchKernelGGL((k_hit_rows<WFA_SRC_SG_FUSED, WW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); break;
+    switch (sg.W) {
+        WFA_ROWS(5)
+        WFA_ROWS(7)
+        WFA_ROWS(9)
+        WFA_ROWS(11)
+        WFA_ROWS(13)
+        WFA_ROWS(15)
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_ROWS
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ struct RecView {
     const int16_t* board;
     const int16_t* chan;
     const int64_t* rid;
+    const int64_t* bm_off;  // byte offset of the record's mask bits in the hit bitmap
 };
 
 struct SgParams {
@@ -41,18 +42,45 @@ struct SgParams {
     int32_t den, den_edge;
     int64_t guard, guard_edge;
     double rden, rden_edge;
+    int32_t margin;       // numerator units covering one float32 ulp of y (candidate band half-width)
+    int32_t margin_edge;  // same for the edge projection rows (den_edge)
 };
 
 struct HitParams {
     int32_t le, re, max_len;
     int32_t bl_start, bl_end;
-    int32_t bm_words;  // LDS words per wave
+    int32_t bm_words;  // LDS bitmap words per wave
     int32_t chunk_rows;
+    int32_t use_fast;  // allow the integer fast path (0 = literal float64 kernel, for A/B tests)
     uint8_t* tmp;
     int64_t tmp_rows;
     unsigned long long* cursor;
     int64_t* rec_tmp_start;
     int32_t* rec_nhits;
+};
+
+// fused mask pass (k_sg_mask)
+struct MaskParams {
+    int32_t bl_start, bl_end;
+    uint8_t* bitmap;
+    int32_t* rec_nhits;
+};
+
+// span mode of the mask pass: all records have length L (multiple of 8, >= 24), are contiguous from
+// pool index off0 (multiple of 8) and share one polarity class
+struct SpanParams {
+    int64_t off0;
+    int32_t L;
+    int32_t positive;
+    int32_t rs;        // records per span (<= 64)
+    int64_t n_spans;
+    int64_t bm_off0;   // bitmap byte offset of record 0
+    int64_t bm_stride; // bitmap bytes per record
+};
+
+// hit-row pass (k_hit_rows)
+struct RowParams {
+    int32_t le, re, max_len;
 };
 
 struct FeatParams {
@@ -78,6 +106,15 @@ hipError_t launch_scan(hipStream_t st, const int32_t* counts, int64_t n, int64_t
                        int64_t* out);
 hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t* tmp_start,
                               const int32_t* nhits, const int64_t* out_start, int64_t R, uint8_t* out);
+bool sg_mask_supported(const SgParams& sg);
+hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
+                          const RecView& rec, const SgParams& sg, const MaskParams& mp);
+hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
+                               const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
+hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
+                           const int64_t* out_start, int4* desc);
+hipError_t launch_hit_rows(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
+                           const RowParams& rp, const int4* desc, int64_t n_hits, uint8_t* out);
 hipError_t launch_basic_features(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const FeatParams& fp, uint8_t* out);
 hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
