@@ -188,18 +188,24 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
         if ((rc = c->hit_out.ensure((size_t)total * 60))) return rc;
         if ((rc = c->hit_desc.ensure((size_t)total * sizeof(int4)))) return rc;
+        RowParams rp{le, re, max_len, sp0.W / 2};
         {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_hit_runs(c->stream, rv0, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
-                                          c->rec_out_start.as<int64_t>(), c->hit_desc.as<int4>()));
+                                          c->rec_out_start.as<int64_t>(), c->hit_desc.as<int4>(), rp));
             if ((rc = t.end("k_hit_runs"))) return rc;
         }
         {
-            RowParams rp{le, re, max_len};
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_hit_rows(c->stream, pv0, rv0, sp0, rp, c->hit_desc.as<int4>(), total,
-                                          c->hit_out.as<uint8_t>()));
-            if ((rc = t.end("k_hit_rows"))) return rc;
+            WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pv0, rv0, sp0, rp, c->hit_desc.as<int4>(), total,
+                                               c->hit_out.as<uint8_t>()));
+            if ((rc = t.end("k_hit_rows_grp"))) return rc;
+        }
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pv0, rv0, sp0, rp,
+                                                  c->hit_desc.as<int4>(), total, true, c->hit_out.as<uint8_t>()));
+            if ((rc = t.end("k_hit_rows_literal"))) return rc;
         }
         WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
         c->n_hits = total;

@@ -950,19 +950,26 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView 
 }
 
 // ---- B1: runs of set bits of every record -> hit descriptors ----------------------------------------
+// desc = (record, start, end, flag); flag 0: record filtered with the full SG window (integer row
+// kernel), 1: literal float64 row kernel (short record / no integer plan).
 __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t* __restrict__ bitmap,
                                                      const int32_t* __restrict__ nhits,
                                                      const int64_t* __restrict__ out_start,
-                                                     int4* __restrict__ desc) {
+                                                     int4* __restrict__ desc, RowParams rp) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= rec.R) return;
     const int n = nhits[r];
     if (n == 0) return;
+    const int L = rec.len[r];
     const int sh = (int)(rec.off[r] & 7);
-    const int nbits = rec.len[r] + sh;
+    const int nbits = L + sh;
     const int nw = (nbits + 63) / 64;
     const uint64_t* __restrict__ bm = reinterpret_cast<const uint64_t*>(bitmap + rec.bm_off[r]);
     int4* __restrict__ out = desc + out_start[r];
+    auto emit = [&](int k, int start, int end) {
+        const bool fast = rp.fast_halo > 0 && L >= 2 * rp.fast_halo + 1;  // record filtered with the full window
+        out[k] = make_int4((int)r, start, end, fast ? 0 : 1);
+    };
     int k = 0;
     int run_start = -1;  // >= 0 while inside a run
     for (int wi = 0; wi < nw && k < n; ++wi) {
@@ -975,17 +982,28 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
             if (run_start < 0) {
                 run_start = wi * 64 + b;
             } else {
-                out[k] = make_int4((int)r, run_start - sh, wi * 64 + b - sh, 0);
+                emit(k, run_start - sh, wi * 64 + b - sh);
                 ++k;
                 run_start = -1;
             }
             pos = b + 1;
         }
     }
-    if (run_start >= 0 && k < n) out[k] = make_int4((int)r, run_start - sh, nw * 64 - sh, 0);
+    if (run_start >= 0 && k < n) emit(k, run_start - sh, nw * 64 - sh);
 }
 
-// ---- B2: one lane per hit -------------------------------------------------------------------------------
+// ---- B2: hit rows ---------------------------------------------------------------------------------------
+// order-independent variant (first maximum by explicit index comparison)
+struct HitAccAny {
+    double best;
+    int best_i;
+    double sum;
+    __device__ __forceinline__ void add(double s, int i) {
+        if (s > best || (s == best && i < best_i)) { best = s; best_i = i; }
+        sum += s > 0.0 ? s : 0.0;
+    }
+};
+
 struct HitAcc {
     double best;
     int best_i;
@@ -996,83 +1014,11 @@ struct HitAcc {
     }
 };
 
-template <int SRC, int W>
-__global__ __launch_bounds__(kBlock) void k_hit_rows(PoolView pool, RecView rec, SgParams sg, RowParams rp,
-                                                     const int4* __restrict__ desc, int64_t n_hits,
-                                                     uint8_t* __restrict__ out) {
-    const int64_t h = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (h >= n_hits) return;
-    const int4 d = desc[h];
-    const int64_t r = d.x;
-    const int start = d.y, end = d.z;
-    const int L = rec.len[r];
-    const int64_t off = rec.off[r];
-    WaveSrc<SRC> src = make_src<SRC>(pool, sg, off, L);
-    HitCtx hc;
-    hc.L = L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
-    hc.thr = rec.thr[r];
-    hc.positive = rec.pol[r] == WFA_POL_POSITIVE;
-    hc.baseline = rec.baseline[r];
-    const int seg_start = start - hc.le > 0 ? start - hc.le : 0;
-    const int seg_end = end + hc.re < hc.max_len ? end + hc.re : hc.max_len;
-
-    HitAcc acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
-    constexpr int H = W / 2;
-    bool done = false;
-    if (SRC == WFA_SRC_SG_FUSED && W > 0) {
-        if (src.sg.w == W && sg.int_ok && seg_start >= H && seg_end <= L - H) {
-            // interior window: integer numerators from aligned 16-byte chunks (3-chunk rolling window)
-            constexpr int NP = (W > 0 ? W : 1) / 2 + 1;
-            uint32_t cpm[NP];
-#pragma unroll
-            for (int m = 0; m < NP; ++m) {
-                const int n0 = sg.itab[2 * m];
-                const int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
-                cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
-            }
-            const int bias_i = 32768 * sg.den;
-            const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
-            const int64_t g0 = off + seg_start, g1 = off + seg_end;  // pool indices
-            int64_t c = g0 >> 3;
-            const int64_t c_last = (g1 - 1) >> 3;
-            const uint4* __restrict__ p16 = reinterpret_cast<const uint4*>(pool.u16);
-            const uint4 zero4 = make_uint4(0, 0, 0, 0);
-            uint4 prev = c > 0 ? p16[c - 1] : zero4;
-            uint4 cur = p16[c];
-            for (; c <= c_last; ++c) {
-                const uint4 nxt = p16[c + 1];  // pool allocation has 256 B of slack
-                uint32_t E[12] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w,
-                                  nxt.x, nxt.y, nxt.z, nxt.w};
-#pragma unroll
-                for (int k = 0; k < 12; ++k) E[k] ^= 0x80008000u;
-                int Z[8];
-                sg_chunk_numerators<(W > 0 ? W : 3)>(E, cpm, Z);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int64_t g = c * 8 + j;
-                    if (g >= g0 && g < g1) {
-                        const int i = (int)(g - off);
-                        const int y_num = Z[j] + bias_i;
-                        float y32;
-                        if (y_num >= guard) y32 = (float)((double)y_num * sg.rden);
-                        else y32 = sg_value_f64(src.xu, L, i, src.sg);
-                        const double sgn = hc.positive ? ((double)y32 - hc.baseline) : (hc.baseline - (double)y32);
-                        acc.add(sgn, i);
-                    }
-                }
-                prev = cur;
-                cur = nxt;
-            }
-            done = true;
-        }
-    }
-    if (!done) {
-        for (int i = seg_start; i < seg_end; ++i) acc.add(hit_signal<SRC>(src, hc, i), i);
-    }
-
+__device__ __forceinline__ void write_hit_row(uint8_t* __restrict__ out, int64_t h, const RecView& rec, int64_t r,
+                                              int L, int start, int end, int seg_start, int seg_end,
+                                              int pos, double best, double sum) {
     const int dt_ns = rec.dt[r];
     const double sip = (double)dt_ns * 1e3;  // hit_finder.py:382
-    const int pos = acc.best_i;
     const int64_t rise = (int64_t)(pos - start > 0 ? pos - start : 0) * dt_ns;
     const int64_t fall = (int64_t)((end - 1) - pos > 0 ? (end - 1) - pos : 0) * dt_ns;
     const int64_t gts = (int64_t)((double)rec.ts[r] + (double)pos * sip);  // :383-386
@@ -1082,8 +1028,8 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows(PoolView pool, RecView rec,
     if (ee < es) ee = es;
     uint32_t* row = reinterpret_cast<uint32_t*>(out + h * 60);
     put_i64(row, 0, (int64_t)pos);
-    put_f32(row, 2, (float)acc.best);
-    put_f32(row, 3, (float)acc.sum);
+    put_f32(row, 2, (float)best);
+    put_f32(row, 3, (float)sum);
     row[4] = (uint32_t)es;
     row[5] = (uint32_t)ee;
     put_f32(row, 6, (float)(double)(ee - es));
@@ -1093,6 +1039,157 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows(PoolView pool, RecView rec,
     put_i64(row, 10, gts);
     row[12] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
     put_i64(row, 13, rec.rid[r]);
+}
+
+// literal path: one lane per hit, float64 code of the reference for every window sample.
+// only_flagged: process descriptors with flag != 0 (the fast kernel did the others).
+template <int SRC>
+__global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecView rec, SgParams sg, RowParams rp,
+                                                             const int4* __restrict__ desc, int64_t n_hits,
+                                                             int only_flagged, uint8_t* __restrict__ out) {
+    const int64_t h = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (h >= n_hits) return;
+    const int4 d = desc[h];
+    if (only_flagged && d.w == 0) return;
+    const int64_t r = d.x;
+    const int start = d.y, end = d.z;
+    const int L = rec.len[r];
+    WaveSrc<SRC> src = make_src<SRC>(pool, sg, rec.off[r], L);
+    HitCtx hc;
+    hc.L = L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
+    hc.thr = rec.thr[r];
+    hc.positive = rec.pol[r] == WFA_POL_POSITIVE;
+    hc.baseline = rec.baseline[r];
+    const int seg_start = start - hc.le > 0 ? start - hc.le : 0;
+    const int seg_end = end + hc.re < hc.max_len ? end + hc.re : hc.max_len;
+    HitAcc acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
+    for (int i = seg_start; i < seg_end; ++i) acc.add(hit_signal<SRC>(src, hc, i), i);
+    write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
+}
+
+// 64-bit values across the 8 lanes of a group with DPP only
+__device__ __forceinline__ double dpp_f64(double v, int ctrl_sel) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(uint32_t)(uint64_t)b, hi = (int)(uint32_t)((uint64_t)b >> 32);
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
+    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ int dpp_i32(int v, int ctrl_sel) {
+    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);                      // row_half_mirror
+}
+
+// fast path: 8 lanes per hit.  Lane q of a group loads the aligned 16-byte chunk (c - 1 + q); lanes
+// 1..6 produce the 8 outputs of their chunk from exact integer numerators (halo over DPP), lanes 0 and
+// 7 only provide halo.  48 window samples per round, one coalesced 128-byte read per group.
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_hit_rows_grp(PoolView pool, RecView rec, SgParams sg, RowParams rp,
+                                                         int4* __restrict__ desc, int64_t n_hits,
+                                                         uint8_t* __restrict__ out) {
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    const int q = threadIdx.x & 7;
+    const int64_t h = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 3;
+    const bool live = h < n_hits;
+    int4 d = make_int4(0, 0, 0, 1);
+    if (live) d = desc[h];
+    const bool work = live && d.w == 0;
+
+    uint32_t cpm[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        const int n0 = sg.itab[2 * m];
+        const int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
+        cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+    }
+    const int bias_i = 32768 * sg.den;
+    const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
+
+    const int64_t r = d.x;
+    const int start = d.y, end = d.z;
+    int L = 0;
+    int64_t off = 0;
+    double baseline = 0.0;
+    bool positive = false;
+    if (work) {
+        L = rec.len[r];
+        off = rec.off[r];
+        baseline = rec.baseline[r];
+        positive = rec.pol[r] == WFA_POL_POSITIVE;
+    }
+    const int seg_start = start - rp.le > 0 ? start - rp.le : 0;
+    const int seg_end = end + rp.re < rp.max_len ? end + rp.re : rp.max_len;
+    // interior part of the window (integer numerators); the <= 2H edge samples and the zero padding
+    // beyond the record (reference's dense matrix) are evaluated literally below
+    const int ilo = seg_start > H ? seg_start : H;
+    const int ihi = seg_end < L - H ? seg_end : L - H;
+    const bool has_int = work && ihi > ilo;
+    const int64_t g0 = off + ilo, g1 = off + ihi;
+    const int64_t c_first = g0 >> 3, c_last = has_int ? ((g1 - 1) >> 3) : -1;
+    const uint4* __restrict__ p16 = reinterpret_cast<const uint4*>(pool.u16);
+
+    HitAccAny acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
+    bool need_literal = false;
+    // rounds: the whole wave iterates while any group has chunks left
+    for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 6) {
+        const int64_t mine = c - 1 + q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c <= c_last && mine >= 0 && mine <= c_last + 1) v = p16[mine];  // pool has 256 B of slack
+        uint32_t E[12];
+        E[4] = v.x ^ 0x80008000u; E[5] = v.y ^ 0x80008000u; E[6] = v.z ^ 0x80008000u; E[7] = v.w ^ 0x80008000u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            E[k] = dpp_from_prev_lane(0u, E[4 + k]);
+            E[8 + k] = dpp_from_next_lane(0u, E[4 + k]);
+        }
+        int Z[8];
+        sg_chunk_numerators<W>(E, cpm, Z);
+        if (q >= 1 && q <= 6 && mine <= c_last) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t g = mine * 8 + j;
+                if (g >= g0 && g < g1) {
+                    const int y_num = Z[j] + bias_i;
+                    need_literal |= y_num < guard;
+                    const float y32 = (float)((double)y_num * sg.rden);
+                    const double sgn = positive ? ((double)y32 - baseline) : (baseline - (double)y32);
+                    acc.add(sgn, (int)(g - off));
+                }
+            }
+        }
+    }
+    if (__ballot(work && (seg_start < H || seg_end > L - H)) != 0) {
+        if (work && (seg_start < H || seg_end > L - H)) {
+            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, off, L);
+            HitCtx hc;
+            hc.L = L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
+            hc.thr = 0.0; hc.positive = positive; hc.baseline = baseline;
+            const int l_end = seg_end < H ? seg_end : H;              // left edge samples [seg_start, l_end)
+            for (int i = seg_start + q; i < l_end; i += 8) acc.add(hit_signal<WFA_SRC_SG_FUSED>(src, hc, i), i);
+            const int r_beg = seg_start > L - H ? seg_start : L - H;  // right edge + padding [r_beg, seg_end)
+            for (int i = r_beg + q; i < seg_end; i += 8) acc.add(hit_signal<WFA_SRC_SG_FUSED>(src, hc, i), i);
+        }
+    }
+    // combine the 8 lanes of the group (butterfly over xor 1, xor 2, mirror)
+#pragma unroll
+    for (int step = 0; step < 3; ++step) {
+        const double ov = dpp_f64(acc.best, step);
+        const int oi = dpp_i32(acc.best_i, step);
+        const double os = dpp_f64(acc.sum, step);
+        const int on = dpp_i32((int)need_literal, step);
+        const bool take = (ov > acc.best) || (ov == acc.best && oi < acc.best_i);
+        acc.best = take ? ov : acc.best;
+        acc.best_i = take ? oi : acc.best_i;
+        acc.sum += os;
+        need_literal |= on != 0;
+    }
+    if (work && q == 0) {
+        if (need_literal) desc[h].w = 2;  // below the integer guard: the literal kernel redoes this hit
+        else write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
+    }
 }
 
 // ---- exclusive scan of per-record hit counts (int32 -> int64 offsets) --------------------------
@@ -1492,19 +1589,19 @@ hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolVi
 }
 
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
-                           const int64_t* out_start, int4* desc) {
+                           const int64_t* out_start, int4* desc, const RowParams& rp) {
     if (rec.R == 0) return hipSuccess;
     const unsigned grid = (unsigned)((rec.R + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kBlock), 0, st, rec, bitmap, nhits, out_start, desc);
+    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kBlock), 0, st, rec, bitmap, nhits, out_start, desc, rp);
     return hipGetLastError();
 }
 
-hipError_t launch_hit_rows(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
-                           const RowParams& rp, const int4* desc, int64_t n_hits, uint8_t* out) {
+hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
+                                const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out) {
     if (n_hits == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((n_hits + kBlock - 1) / kBlock);
+    const unsigned grid = (unsigned)((n_hits * 8 + kBlock - 1) / kBlock);
 #define WFA_ROWS(WW) \
-    case WW: hipLaunchKernelGGL((k_hit_rows<WFA_SRC_SG_FUSED, WW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); break;
+    case WW: hipLaunchKernelGGL((k_hit_rows_grp<WW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); break;
     switch (sg.W) {
         WFA_ROWS(5)
         WFA_ROWS(7)
@@ -1515,6 +1612,21 @@ hipError_t launch_hit_rows(hipStream_t st, const PoolView& pool, const RecView& 
         default: return hipErrorInvalidValue;
     }
 #undef WFA_ROWS
+    return hipGetLastError();
+}
+
+hipError_t launch_hit_rows_literal(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
+                                   const SgParams& sg, const RowParams& rp, const int4* desc, int64_t n_hits,
+                                   bool only_flagged, uint8_t* out) {
+    if (n_hits == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_hits + kBlock - 1) / kBlock);
+    const int flag = only_flagged ? 1 : 0;
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_hit_rows_literal<WFA_SRC_RAW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, flag, out);
+    else if (source == WFA_SRC_F32)
+        hipLaunchKernelGGL((k_hit_rows_literal<WFA_SRC_F32>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, flag, out);
+    else
+        hipLaunchKernelGGL((k_hit_rows_literal<WFA_SRC_SG_FUSED>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, flag, out);
     return hipGetLastError();
 }
 

@@ -81,6 +81,7 @@ struct SpanParams {
 // hit-row pass (k_hit_rows)
 struct RowParams {
     int32_t le, re, max_len;
+    int32_t fast_halo;  // SG half window when the integer row kernel may be used, else 0
 };
 
 struct FeatParams {
@@ -112,9 +113,12 @@ hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, cons
 hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
-                           const int64_t* out_start, int4* desc);
-hipError_t launch_hit_rows(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
-                           const RowParams& rp, const int4* desc, int64_t n_hits, uint8_t* out);
+                           const int64_t* out_start, int4* desc, const RowParams& rp);
+hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
+                                const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out);
+hipError_t launch_hit_rows_literal(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
+                                   const SgParams& sg, const RowParams& rp, const int4* desc, int64_t n_hits,
+                                   bool only_flagged, uint8_t* out);
 hipError_t launch_basic_features(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const FeatParams& fp, uint8_t* out);
 hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
