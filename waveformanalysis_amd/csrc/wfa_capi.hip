@@ -167,6 +167,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             sp.rs = 64;
             sp.n_spans = (R + sp.rs - 1) / sp.rs;
             sp.bm_off0 = 0;
+            sp.dbg = getenv("WFA_SPAN_DBG") ? atoi(getenv("WFA_SPAN_DBG")) : 0;
             sp.bm_stride = ((int64_t)c->span_L + 7 + 63) / 64 * 8 + 8;
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));

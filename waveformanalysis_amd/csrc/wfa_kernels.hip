@@ -17,6 +17,9 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
+#ifndef WFA_SPAN_WAVES
+#define WFA_SPAN_WAVES 4  // waves per SIMD the span kernel is register-budgeted for (6 and 8 measured slower)
+#endif
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
@@ -774,25 +777,33 @@ __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, cons
         // edges: integer projection rows (LDS, broadcast reads) on the first / last W samples
         int zhi_e, zlo_e;
         int_band(positive, baseline, thr, (double)sg.den_edge, 0.0, sg.margin_edge, zhi_e, zlo_e);
-        const uint4 a0 = p[0], a1 = p[1], b0 = p[(L >> 3) - 2], b1 = p[(L >> 3) - 1];
-        const uint32_t da[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const uint32_t db[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        int xl[W], xr[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            xl[k] = (int)((da[k >> 1] >> (16 * (k & 1))) & 0xffffu);
-            const int q = 16 - W + k;  // last W of the last 16 samples
-            xr[k] = (int)((db[q >> 1] >> (16 * (q & 1))) & 0xffffu);
-        }
         uint32_t border_e = 0;
-        for (int e = 0; e < 2 * H; ++e) {
-            int acc = 0;
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {  // left edge, then right edge (same registers)
+            const uint4 c0 = side == 0 ? p[0] : p[(L >> 3) - 2];
+            const uint4 c1 = side == 0 ? p[1] : p[(L >> 3) - 1];
+            const uint32_t dw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            int xw[W];
 #pragma unroll
-            for (int k = 0; k < W; ++k) acc += etab[e * W + k] * (e < H ? xl[k] : xr[k]);
-            const int ze = positive ? -acc : acc;
-            const bool m = ze < zhi_e;
-            eb |= (int)m << e;
-            border_e |= (uint32_t)(m && ze > zlo_e) << e;
+            for (int k = 0; k < W; ++k) {
+                const int q = side == 0 ? k : 16 - W + k;  // first W / last W of the 16 samples
+                const int q0 = k, q1 = 16 - W + k;
+                const uint32_t lo = (dw[q0 >> 1] >> (16 * (q0 & 1))) & 0xffffu;
+                const uint32_t hi = (dw[q1 >> 1] >> (16 * (q1 & 1))) & 0xffffu;
+                (void)q;
+                xw[k] = (int)(side == 0 ? lo : hi);
+            }
+#pragma unroll 1
+            for (int eh = 0; eh < H; ++eh) {
+                const int e = side * H + eh;
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc += etab[e * W + k] * xw[k];
+                const int ze = positive ? -acc : acc;
+                const bool m = ze < zhi_e;
+                eb |= (int)m << e;
+                border_e |= (uint32_t)(m && ze > zlo_e) << e;
+            }
         }
         if (border_e) {  // rare: float64 reference code decides
             WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * L, L);
@@ -810,7 +821,7 @@ __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, cons
 }
 
 template <int W, bool FUSED_BASELINE>
-__global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView rec, SgParams sg,
+__global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolView pool, RecView rec, SgParams sg,
                                                          MaskParams mp, SpanParams sp) {
     constexpr int H = W / 2;
     constexpr int NP = H + 1;
@@ -850,24 +861,24 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView 
         // ================= phase 1: tiles over the span's sample stream =================
         const int span_samples = nrec * L;
         const int T = (span_samples + 511) / 512;
+        // sp.dbg (measurement only): bit1 = every span streams span 0's samples (cache resident)
+        const uint16_t* __restrict__ span_ptr = pool.u16 + ((sp.dbg & 2) ? sp.off0 : g_base);
+        const int last_chunk_pos = span_samples - 8;  // loads beyond the span re-read its last chunk
         auto tile_at = [&](int t) {
+            int pos = t * 512 + lane * 8;
+            pos = pos < last_chunk_pos ? pos : last_chunk_pos;
+            const uint4 v = *reinterpret_cast<const uint4*>(span_ptr + pos);
             Tile x;
-            const int pos = t * 512 + lane * 8;
-            if (t < T && pos < span_samples) {
-                const uint4 v = pool16[((g_base + pos) >> 3)];
-                x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
-            } else {
-                x.d[0] = x.d[1] = x.d[2] = x.d[3] = fill_raw;
-            }
+            x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
             return x;
         };
         int rl = (lane * 8) / L;        // record (within the span) of this lane's chunk
         int i0 = lane * 8 - rl * L;     // position of the chunk inside its record (multiple of 8)
         uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;
         uint32_t carry_msb = 0;
-        Tile cur = tile_at(0), nxt = tile_at(1), nn = tile_at(2);
-        for (int t = 0; t < T; ++t) {
-            const Tile fut = tile_at(t + 3);
+        uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
+
+        auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
             const bool in_span = t * 512 + lane * 8 < span_samples;
             const int rli = in_span ? rl : 0;
             const int zhi = in_span ? tab->zhi[rli] : INT32_MIN;
@@ -888,19 +899,24 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView 
             E[10] = dpp_from_next_lane(n2, E[6]);
             E[11] = dpp_from_next_lane(n3, E[7]);
             int Z[8];
-            sg_chunk_numerators<W>(E, cpm, Z);
-
-            // interior outputs of this chunk: all 8, except next to a record boundary
-            const bool first = i0 == 0, last = i0 == L - 8;
-            const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
-            bool cand = false;
+            if (sp.dbg & 1) {  // measurement only: no filter arithmetic
 #pragma unroll
-            for (int j = 0; j < 8; ++j) cand |= Z[j] < zhi;
-            const int ebr = (in_span && (first || last)) ? tab->eb[rli] : 0;
-            const uint32_t ebits = first ? ((uint32_t)ebr & ((1u << H) - 1u))
-                                         : (last ? (((uint32_t)ebr >> H) << (8 - H)) & 0xffu : 0u);
+                for (int j = 0; j < 8; ++j) Z[j] = (int)(E[2 + j] >> 1) + 0x40000000;
+            } else {
+                sg_chunk_numerators<W>(E, cpm, Z);
+            }
+
+            // candidates: 8 compares into lane masks, OR-ed on the scalar unit
+            uint64_t cm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cm[j] = __ballot(Z[j] < zhi);
+            const uint64_t any_c = cm[0] | cm[1] | cm[2] | cm[3] | cm[4] | cm[5] | cm[6] | cm[7];
+            const bool first = i0 == 0, last = i0 == L - 8;
+            const uint64_t edge_lanes = __ballot(in_span && (first || last));
             uint32_t byte = 0;
-            if (__ballot(cand || ebits != 0) != 0) {
+            if (any_c != 0 || edge_lanes != 0) {
+                // interior outputs of this chunk: all 8, except next to a record boundary
+                const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
                 const int zlo = tab->zlo[rli];
                 uint32_t border = 0;
 #pragma unroll
@@ -924,7 +940,10 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView 
                         }
                     }
                 }
-                byte |= ebits;
+                if (in_span && (first || last)) {
+                    const uint32_t ebr = (uint32_t)tab->eb[rli];
+                    byte |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (8 - H)) & 0xffu;
+                }
                 if (__ballot(byte != 0) != 0) {
                     // run starts: a set bit whose predecessor (same record) is clear
                     uint32_t prevb = dpp_from_prev_lane(carry_msb << 7, byte);
@@ -933,16 +952,27 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span(PoolView pool, RecView 
                     if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
                 }
             }
-            if (in_span) mp.bitmap[sp.bm_off0 + (r0 + rl) * sp.bm_stride + (i0 >> 3)] = (uint8_t)byte;
+            if (in_span) bm_span[rl * (int)sp.bm_stride + (i0 >> 3)] = (uint8_t)byte;
             carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
             p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
             p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
             p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
             p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
-            cur = nxt; nxt = nn; nn = fut;
             i0 += 512;
             while (i0 >= L) { i0 -= L; ++rl; }
+        };
+        // ring of 4 tiles, 3 loads in flight; unrolled by 4 so the ring never moves registers
+        Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
+        int t = 0;
+        for (; t + 4 <= T; t += 4) {
+            rd = tile_at(t + 3); do_tile(t, ra, rb);
+            ra = tile_at(t + 4); do_tile(t + 1, rb, rc);
+            rb = tile_at(t + 5); do_tile(t + 2, rc, rd);
+            rc = tile_at(t + 6); do_tile(t + 3, rd, ra);
         }
+        if (t < T) { rd = tile_at(t + 3); do_tile(t, ra, rb); ++t; }
+        if (t < T) { do_tile(t, rb, rc); ++t; }
+        if (t < T) { do_tile(t, rc, rd); ++t; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane < nrec) mp.rec_nhits[r0 + lane] = tab->nr[lane];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1564,9 +1594,12 @@ hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, cons
 
 hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
+    // persistent waves: exactly the resident set (256 CUs x WFA_SPAN_WAVES waves/SIMD), spans are dealt
+    // round-robin, so a wave never starts a second "round" of blocks
     int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t resident = 256 * WFA_SPAN_WAVES;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
+    if (g > resident) g = resident;
     const int grid = (int)g;
 #define WFA_SPAN(WW)                                                                                              \
     case WW:                                                                                                      \

@@ -76,6 +76,7 @@ struct SpanParams {
     int64_t n_spans;
     int64_t bm_off0;   // bitmap byte offset of record 0
     int64_t bm_stride; // bitmap bytes per record
+    int32_t dbg;       // measurement knobs (0 in production)
 };
 
 // hit-row pass (k_hit_rows)
