@@ -98,6 +98,7 @@ static SgParams sg_params(wfa_ctx* c) {
     // |y| < 2^17 for uint16 samples (sum|c| < 2): float32 ulp <= 2^-7
     s.margin = (int32_t)((c->sg.den + 127) / 128 + 2);
     s.margin_edge = (int32_t)((c->sg.den_edge + 127) / 128 + 2);
+    s.mfma_tab = c->sg.mfma_ok ? c->sg.mfma.as<int8_t>() : nullptr;
     return s;
 }
 
@@ -170,8 +171,13 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             sp.dbg = getenv("WFA_SPAN_DBG") ? atoi(getenv("WFA_SPAN_DBG")) : 0;
             sp.bm_stride = ((int64_t)c->span_L + 7 + 63) / 64 * 8 + 8;
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
-            if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
+            if (sg_mask_mfma_supported(sp0, c->span_L) && getenv("WFA_ENABLE_MFMA")) {  // experiment, see DESIGN.md
+                WFA_HIP_CHECK(launch_sg_mask_span_mfma(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+                if ((rc = t.end(fused_bl ? "k_sg_mask_span_mfma<baseline>" : "k_sg_mask_span_mfma"))) return rc;
+            } else {
+                WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+                if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
+            }
         } else {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_sg_mask(c->stream, fused_bl, c->max_len, pv0, rv0, sp0, mp));
@@ -334,7 +340,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
-                      &c->hit_desc, &c->sg.tab,
+                      &c->hit_desc, &c->sg.mfma, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
@@ -475,6 +481,37 @@ int wfa_set_sg_plan(wfa_ctx* c, int window, int polyorder, const double* tab, co
         if ((rc = h2d(c, s.itab, itab, isz))) return rc;
     } else {
         if ((rc = s.itab.ensure(isz))) return rc;
+    }
+    // band matrices of the matrix-core mask kernel, in MFMA operand layout:
+    // [polarity 0 (+n) / 1 (-n)][shift prev, own, next][set a, b][part P (low bytes), Q (high bytes)][lane][16]
+    s.mfma_ok = false;
+    if (int_ok && window >= 5 && window <= 15) {
+        bool fits = true;
+        for (int k = 0; k < window; ++k) fits = fits && itab[k] >= -127 && itab[k] <= 127;
+        if (fits) {
+            std::vector<int8_t> bt((size_t)2 * 12 * 64 * 16, 0);
+            const int Hh = window / 2;
+            for (int pol = 0; pol < 2; ++pol)
+                for (int shift = 0; shift < 3; ++shift)
+                    for (int set = 0; set < 2; ++set)
+                        for (int part = 0; part < 2; ++part)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 16; ++j) {
+                                    const int col = lane & 15, kq = lane >> 4;  // B[k = 16 kq + j][col]
+                                    const int want_q = 2 * set + (col >> 3);    // quarter feeding this column
+                                    const int sample = j >> 1, byte = j & 1, out = col & 7;
+                                    int v = 0;
+                                    if (kq == want_q && byte == part) {
+                                        const int tap = sample + 8 * (shift - 1) - out + Hh;
+                                        if (tap >= 0 && tap < window) v = pol ? -itab[tap] : itab[tap];
+                                    }
+                                    const size_t m = (size_t)(((pol * 3 + shift) * 2 + set) * 2 + part);
+                                    bt[(m * 64 + lane) * 16 + j] = (int8_t)v;
+                                }
+            if ((rc = h2d(c, s.mfma, bt.data(), bt.size()))) return rc;
+            WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+            s.mfma_ok = true;
+        }
     }
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_sg = true;

@@ -55,6 +55,8 @@ struct SgPlanDev {
     DevBuf tab;   // double
     DevBuf itab;  // int32
     DevBuf sym;   // uint8
+    DevBuf mfma;  // int8 band matrices (see k_sg_mask_span_mfma)
+    bool mfma_ok = false;
     std::vector<uint8_t> sym_host;
 };
 

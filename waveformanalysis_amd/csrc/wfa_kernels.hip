@@ -739,14 +739,13 @@ template <int W, bool FUSED_BASELINE>
 __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, const RecView& rec, const SgParams& sg,
                                                       const MaskParams& mp, const int32_t* __restrict__ etab,
                                                       int64_t g_base, int64_t r0, int nrec, int L, bool positive,
-                                                      SpanTable* __restrict__ tab) {
+                                                      double bias, SpanTable* __restrict__ tab) {
     constexpr int H = W / 2;
     const int lane = lane_id();
     const int64_t r = r0 + lane;
     int zhi = INT32_MIN, zlo = INT32_MIN, eb = 0;
     double baseline = 0.0, thr = 0.0;
     if (lane < nrec) {
-        const double bias = 32768.0 * (double)sg.den;
         const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * L) >> 3);
         thr = rec.thr[r];
         if (FUSED_BASELINE) {
@@ -848,14 +847,14 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
     }
     const uint32_t fill_raw = positive ? 0u : 0xffffffffu;
     const uint32_t fillb = fill_raw ^ 0x80008000u;
-    const uint4* __restrict__ pool16 = reinterpret_cast<const uint4*>(pool.u16);
 
     for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
         const int64_t r0 = span * sp.rs;
         const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
         const int64_t g_base = sp.off0 + r0 * L;  // pool index of the span's first sample (multiple of 8)
 
-        span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive, tab);
+        span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
+                                       32768.0 * (double)sg.den, tab);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
         // ================= phase 1: tiles over the span's sample stream =================
@@ -877,6 +876,8 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
         uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;
         uint32_t carry_msb = 0;
         uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
+        int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);       // byte of this lane's chunk in the span's bitmap
+        const int bm_wrap = (int)sp.bm_stride - (L >> 3);      // added when the lane moves to the next record
 
         auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
             const bool in_span = t * 512 + lane * 8 < span_samples;
@@ -915,6 +916,10 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
             const uint64_t edge_lanes = __ballot(in_span && (first || last));
             uint32_t byte = 0;
             if (any_c != 0 || edge_lanes != 0) {
+                // keep the branch body out of the straight-line path (hipcc otherwise speculates the
+                // byte assembly above the branch, ~25 VALU per tile that half of the tiles do not need)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(Z[j]));
                 // interior outputs of this chunk: all 8, except next to a record boundary
                 const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
                 const int zlo = tab->zlo[rli];
@@ -952,16 +957,230 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
                     if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
                 }
             }
-            if (in_span) bm_span[rl * (int)sp.bm_stride + (i0 >> 3)] = (uint8_t)byte;
+            if (in_span) bm_span[bm_pos] = (uint8_t)byte;
             carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
             p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
             p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
             p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
             p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
             i0 += 512;
-            while (i0 >= L) { i0 -= L; ++rl; }
+            bm_pos += 64;
+            while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
         };
         // ring of 4 tiles, 3 loads in flight; unrolled by 4 so the ring never moves registers
+        Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
+        int t = 0;
+        for (; t + 4 <= T; t += 4) {
+            rd = tile_at(t + 3); do_tile(t, ra, rb);
+            ra = tile_at(t + 4); do_tile(t + 1, rb, rc);
+            rb = tile_at(t + 5); do_tile(t + 2, rc, rd);
+            rc = tile_at(t + 6); do_tile(t + 3, rd, ra);
+        }
+        if (t < T) { rd = tile_at(t + 3); do_tile(t, ra, rb); ++t; }
+        if (t < T) { do_tile(t, rb, rc); ++t; }
+        if (t < T) { do_tile(t, rc, rd); ++t; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < nrec) mp.rec_nhits[r0 + lane] = tab->nr[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ---- A (span mode, matrix cores): the FIR as a banded matrix product -----------------------------------
+// Same contract as k_sg_mask_span, for L % 32 == 0 and |n_k| <= 127.  Measured: the integer VALU issues
+// one wave64 op per ~4.2 cycles (tools/valu_rate.hip), so 48 dot2 + 9 perm per tile make the dot2 kernel
+// VALU-bound at ~0.36 of HBM peak.  Here the 11-tap sums run on v_mfma_i32_16x16x64_i8:
+//   A (16 x 64 bytes)  = the wave's 64 loaded chunks as they sit in registers: lane l = 16q + r holds
+//                        chunk l = k-quarter q of row r (bytes biased by -128 with one xor per dword),
+//   B (64 x 16)        = host-built band matrix: k-quarter 0/1 (set a) or 2/3 (set b) -> 8 output
+//                        columns each, rows of the low bytes (P) or the high bytes (Q) carry n[tap],
+//   D (16 x 16 int32)  = partial sums; numerator Z = P + 256 Q (+ constant folded into the band).
+// Three A operands (previous / own / next chunk, halo over DPP) x {a,b} x {P,Q} = 12 MFMAs per tile.
+// A compare on D register i gives a 64-bit lane mask whose 8 bytes ARE the mask bytes of 8 chunks.
+typedef int wfa_v4i __attribute__((ext_vector_type(4)));
+
+template <int W, bool FUSED_BASELINE>
+__global__ __launch_bounds__(kBlock) void k_sg_mask_span_mfma(PoolView pool, RecView rec, SgParams sg,
+                                                              MaskParams mp, SpanParams sp) {
+    constexpr int H = W / 2;
+    __shared__ SpanTable s_tab[kWavesPerBlock];
+    __shared__ int32_t etab[2 * H * W];
+    __shared__ uint64_t s_words[kWavesPerBlock][8];
+    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
+    __syncthreads();
+    const int lane = lane_id();
+    const int wv = wave_in_block();
+    SpanTable* tab = &s_tab[wv];
+    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int L = sp.L;
+    const bool positive = sp.positive != 0;
+
+    // band matrices in operand layout: [polarity][shift prev/own/next][set a/b][part P/Q][lane] x 16 B
+    const wfa_v4i* __restrict__ btab = reinterpret_cast<const wfa_v4i*>(sg.mfma_tab) + (positive ? 12 * 64 : 0);
+    wfa_v4i B[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) B[k] = btab[k * 64 + lane];
+    const double bias = 32896.0 * (double)sg.den;  // 128 * (1 + 256) * sum(n)
+    const int bias_i = 32896 * sg.den;
+    const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
+    const uint32_t fillb = (positive ? 0u : 0xffffffffu) ^ 0x80808080u;
+
+    // scattered (result) layout of this lane: column c = lane & 15, row group g = lane >> 4;
+    // D register i of set a <-> chunk 4g + 16h + i, sample c & 7 (h = c >> 3); set b: + 32 chunks
+    const int qa = 4 * (lane >> 4) + 16 * ((lane >> 3) & 1);
+    // natural layout -> (word, byte) of the ballot words holding this lane's chunk
+    const int nat_word = 4 * (lane >> 5) + (lane & 3);
+    const int nat_byte = 2 * ((lane & 15) >> 2) + ((lane >> 4) & 1);
+
+    for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
+        const int64_t r0 = span * sp.rs;
+        const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
+        const int64_t g_base = sp.off0 + r0 * L;
+        span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive, bias, tab);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        const int span_samples = nrec * L;
+        const int T = (span_samples + 511) / 512;
+        const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
+        const int last_chunk_pos = span_samples - 8;
+        auto tile_at = [&](int t) {
+            int pos = t * 512 + lane * 8;
+            pos = pos < last_chunk_pos ? pos : last_chunk_pos;
+            const uint4 v = *reinterpret_cast<const uint4*>(span_ptr + pos);
+            Tile x;
+            x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
+            return x;
+        };
+        // natural layout bookkeeping (lane = chunk): record, position, bitmap byte
+        int rl = (lane * 8) / L;
+        int i0 = lane * 8 - rl * L;
+        uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
+        int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);
+        const int bm_wrap = (int)sp.bm_stride - (L >> 3);
+        // scattered layout bookkeeping: record of the 4-chunk groups of set a / set b (L % 32 == 0)
+        int rla = (qa * 8) / L, ia = qa * 8 - rla * L;
+        int rlb = (qa * 8 + 256) / L, ib = qa * 8 + 256 - rlb * L;
+        uint32_t p1 = fillb, p2 = fillb, p3 = fillb;
+        uint32_t carry_msb = 0;
+
+        auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
+            wfa_v4i a_own, a_prev, a_next;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a_own[k] = (int)(cur.d[k] ^ 0x80808080u);
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80808080u;
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80808080u;
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80808080u;
+            a_prev[0] = a_own[0];  // samples 0,1 of the previous chunk are outside every window (H <= 7... B rows are 0)
+            a_prev[1] = (int)dpp_from_prev_lane(p1, (uint32_t)a_own[1]);
+            a_prev[2] = (int)dpp_from_prev_lane(p2, (uint32_t)a_own[2]);
+            a_prev[3] = (int)dpp_from_prev_lane(p3, (uint32_t)a_own[3]);
+            a_next[0] = (int)dpp_from_next_lane(n0, (uint32_t)a_own[0]);
+            a_next[1] = (int)dpp_from_next_lane(n1, (uint32_t)a_own[1]);
+            a_next[2] = (int)dpp_from_next_lane(n2, (uint32_t)a_own[2]);
+            a_next[3] = a_own[3];
+            const wfa_v4i zero = {0, 0, 0, 0};
+            wfa_v4i Pa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[0], zero, 0, 0, 0);
+            wfa_v4i Qa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[1], zero, 0, 0, 0);
+            wfa_v4i Pb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[2], zero, 0, 0, 0);
+            wfa_v4i Qb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[3], zero, 0, 0, 0);
+            Pa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[4], Pa, 0, 0, 0);
+            Qa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[5], Qa, 0, 0, 0);
+            Pb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[6], Pb, 0, 0, 0);
+            Qb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[7], Qb, 0, 0, 0);
+            Pa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[8], Pa, 0, 0, 0);
+            Qa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[9], Qa, 0, 0, 0);
+            Pb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[10], Pb, 0, 0, 0);
+            Qb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[11], Qb, 0, 0, 0);
+
+            const bool in_a = t * 512 + qa * 8 < span_samples, in_b = t * 512 + qa * 8 + 256 < span_samples;
+            const int rla_i = in_a ? rla : 0, rlb_i = in_b ? rlb : 0;
+            const int zhi_a = in_a ? tab->zhi[rla_i] : INT32_MIN, zhi_b = in_b ? tab->zhi[rlb_i] : INT32_MIN;
+            int Z[8];
+            uint64_t cm[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Z[i] = Pa[i] + (Qa[i] << 8);
+                Z[4 + i] = Pb[i] + (Qb[i] << 8);
+                cm[i] = __ballot(Z[i] < zhi_a);
+                cm[4 + i] = __ballot(Z[4 + i] < zhi_b);
+            }
+            const uint64_t any_c = cm[0] | cm[1] | cm[2] | cm[3] | cm[4] | cm[5] | cm[6] | cm[7];
+            const bool in_span = t * 512 + lane * 8 < span_samples;
+            const bool first = i0 == 0, last = i0 == L - 8;
+            const uint64_t edge_lanes = __ballot(in_span && (first || last) && tab->eb[in_span ? rl : 0] != 0);
+            uint32_t byte = 0;
+            if (any_c != 0 || edge_lanes != 0) {
+                // borderline elements (inside the band): the float64 predicate of the reference on
+                // y = f32(Y/den); Y >= guard always holds here or the element is left to the literal check
+                const int zlo_a = tab->zlo[rla_i], zlo_b = tab->zlo[rlb_i];
+                uint64_t bd[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bd[i] = __ballot(Z[i] < zhi_a && Z[i] > zlo_a);
+                    bd[4 + i] = __ballot(Z[4 + i] < zhi_b && Z[4 + i] > zlo_b);
+                }
+                if ((bd[0] | bd[1] | bd[2] | bd[3] | bd[4] | bd[5] | bd[6] | bd[7]) != 0) {
+                    const double bl_a = tab->bl[rla_i], th_a = tab->thr[rla_i];
+                    const double bl_b = tab->bl[rlb_i], th_b = tab->thr[rlb_i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (bd[i] == 0) continue;
+                        const bool isb = i >= 4;
+                        const int zlo = isb ? zlo_b : zlo_a, zhi = isb ? zhi_b : zhi_a;
+                        bool m = Z[i] < zhi;
+                        if (m && Z[i] > zlo) {
+                            const int y_num = (positive ? -Z[i] : Z[i]) + bias_i;
+                            const double bl = isb ? bl_b : bl_a, th = isb ? th_b : th_a;
+                            if (y_num >= guard) {
+                                const double y = (double)(float)((double)y_num * sg.rden);
+                                m = (positive ? (y - bl) : (bl - y)) >= th;
+                            } else {  // below the integer guard: literal float64 chain
+                                const int rli = isb ? rlb_i : rla_i;
+                                const int pos_in_rec = (isb ? ib : ia) + 8 * (i & 3) + (lane & 7);
+                                WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
+                                const double w = src.at(pos_in_rec);
+                                m = (positive ? (w - bl) : (bl - w)) >= th;
+                            }
+                        }
+                        cm[i] = __ballot(m);
+                    }
+                }
+                // natural layout: this lane's chunk byte out of the 8 mask words
+                if (lane < 8) {
+                    uint64_t w = cm[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) w = lane == k ? cm[k] : w;
+                    s_words[wv][lane] = w;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                byte = reinterpret_cast<const uint8_t*>(&s_words[wv][0])[nat_word * 8 + nat_byte];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
+                byte &= vb;
+                if (!in_span) byte = 0;
+                if (in_span && (first || last)) {
+                    const uint32_t ebr = (uint32_t)tab->eb[rl];
+                    byte |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (8 - H)) & 0xffu;
+                }
+                if (__ballot(byte != 0) != 0) {
+                    uint32_t prevb = dpp_from_prev_lane(carry_msb << 7, byte);
+                    if (first) prevb = 0;
+                    const uint32_t starts = byte & ~((byte << 1) | (prevb >> 7)) & 0xffu;
+                    if (starts) atomicAdd(&tab->nr[rl], __popc(starts));
+                }
+            }
+            if (in_span) bm_span[bm_pos] = (uint8_t)byte;
+            carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
+            p1 = (uint32_t)__builtin_amdgcn_readlane(a_own[1], 63);
+            p2 = (uint32_t)__builtin_amdgcn_readlane(a_own[2], 63);
+            p3 = (uint32_t)__builtin_amdgcn_readlane(a_own[3], 63);
+            i0 += 512; bm_pos += 64;
+            while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
+            ia += 512;
+            while (ia >= L) { ia -= L; ++rla; }
+            ib += 512;
+            while (ib >= L) { ib -= L; ++rlb; }
+        };
         Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
         int t = 0;
         for (; t + 4 <= T; t += 4) {
@@ -1589,6 +1808,37 @@ hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, cons
     }
 #undef WFA_MASK
 #undef WFA_MASK2
+    return hipGetLastError();
+}
+
+bool sg_mask_mfma_supported(const SgParams& sg, int L) {
+    return sg.mfma_tab != nullptr && (L % 32) == 0 && sg.W >= 5 && sg.W <= 15;
+}
+
+hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
+                                    const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
+    int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t resident = 256 * WFA_SPAN_WAVES;
+    if (g < 1) g = 1;
+    if (g > resident) g = resident;
+    const int grid = (int)g;
+#define WFA_SPANM(WW)                                                                                                  \
+    case WW:                                                                                                           \
+        if (fused_baseline)                                                                                            \
+            hipLaunchKernelGGL((k_sg_mask_span_mfma<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp);  \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_sg_mask_span_mfma<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp); \
+        break;
+    switch (sg.W) {
+        WFA_SPANM(5)
+        WFA_SPANM(7)
+        WFA_SPANM(9)
+        WFA_SPANM(11)
+        WFA_SPANM(13)
+        WFA_SPANM(15)
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_SPANM
     return hipGetLastError();
 }
 

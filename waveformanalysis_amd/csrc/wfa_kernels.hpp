@@ -44,6 +44,7 @@ struct SgParams {
     double rden, rden_edge;
     int32_t margin;       // numerator units covering one float32 ulp of y (candidate band half-width)
     int32_t margin_edge;  // same for the edge projection rows (den_edge)
+    const int8_t* mfma_tab;  // band matrices for v_mfma_i32_16x16x64_i8 (2 x 12 x 64 x 16 B) or nullptr
 };
 
 struct HitParams {
@@ -113,6 +114,9 @@ hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, cons
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);
 hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
+bool sg_mask_mfma_supported(const SgParams& sg, int L);
+hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
+                                    const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
                            const int64_t* out_start, int4* desc, const RowParams& rp);
 hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
