@@ -916,10 +916,6 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
             const uint64_t edge_lanes = __ballot(in_span && (first || last));
             uint32_t byte = 0;
             if (any_c != 0 || edge_lanes != 0) {
-                // keep the branch body out of the straight-line path (hipcc otherwise speculates the
-                // byte assembly above the branch, ~25 VALU per tile that half of the tiles do not need)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(Z[j]));
                 // interior outputs of this chunk: all 8, except next to a record boundary
                 const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
                 const int zlo = tab->zlo[rli];
@@ -1205,7 +1201,23 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
                                                      const int32_t* __restrict__ nhits,
                                                      const int64_t* __restrict__ out_start,
                                                      int4* __restrict__ desc, RowParams rp) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // The mask regions of a block's 256 records are contiguous (bm_off is cumulative): stage them in
+    // LDS with coalesced 16-byte loads when they fit, so the per-lane bit scan never waits on HBM.
+    constexpr int kStageBytes = 48 * 1024;
+    __shared__ uint4 s_bm[kStageBytes / 16];
+    const int64_t r_first = (int64_t)blockIdx.x * kBlock;
+    const int64_t r_last = r_first + kBlock < rec.R ? r_first + kBlock : rec.R;  // exclusive
+    const int64_t b_first = rec.bm_off[r_first];
+    const int64_t b_last = rec.bm_off[r_last - 1] + (((int64_t)rec.len[r_last - 1] + 7 + 63) / 64 * 8 + 8);
+    const bool staged = (b_last - b_first) <= kStageBytes;  // b_first is a multiple of 8, regions are 8-byte multiples
+    if (staged) {
+        const int64_t a_first = b_first & ~15ll;  // 16-byte aligned start (bitmap buffer is 256-byte aligned)
+        const int n16 = (int)((b_last - a_first + 15) >> 4);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bitmap + a_first);
+        for (int k = threadIdx.x; k < n16 && k < kStageBytes / 16; k += kBlock) s_bm[k] = src[k];
+        __syncthreads();
+    }
+    const int64_t r = r_first + threadIdx.x;
     if (r >= rec.R) return;
     const int n = nhits[r];
     if (n == 0) return;
@@ -1213,7 +1225,10 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
     const int sh = (int)(rec.off[r] & 7);
     const int nbits = L + sh;
     const int nw = (nbits + 63) / 64;
-    const uint64_t* __restrict__ bm = reinterpret_cast<const uint64_t*>(bitmap + rec.bm_off[r]);
+    const bool use_lds = staged && (rec.bm_off[r] - (b_first & ~15ll)) + (int64_t)nw * 8 <= kStageBytes;
+    const uint64_t* __restrict__ bm =
+        use_lds ? reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(s_bm) + (rec.bm_off[r] - (b_first & ~15ll)))
+                : reinterpret_cast<const uint64_t*>(bitmap + rec.bm_off[r]);
     int4* __restrict__ out = desc + out_start[r];
     auto emit = [&](int k, int start, int end) {
         const bool fast = rp.fast_halo > 0 && L >= 2 * rp.fast_halo + 1;  // record filtered with the full window
@@ -1382,6 +1397,14 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_grp(PoolView pool, RecView 
 
     HitAccAny acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
     bool need_literal = false;
+    // Interior samples: sig = +-(b - f64(y32)) is strictly monotone in y32 as long as the float64
+    // subtraction is exact, which holds for |b| < 2^18 and |y| < 2^17 (difference needs < 53 bits).
+    // Then the first maximum of sig is the first extremum of y32: a float32 compare per sample
+    // instead of a float64 compare chain; sig itself is only needed for the integral.
+    const bool y_order = fabs(baseline) < 262144.0;
+    float ext_y = positive ? -__builtin_huge_valf() : __builtin_huge_valf();
+    int ext_i = 0x7fffffff;
+    const int wlen = ihi - ilo;
     // rounds: the whole wave iterates while any group has chunks left
     for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 6) {
         const int64_t mine = c - 1 + q;
@@ -1397,18 +1420,30 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_grp(PoolView pool, RecView 
         int Z[8];
         sg_chunk_numerators<W>(E, cpm, Z);
         if (q >= 1 && q <= 6 && mine <= c_last) {
+            const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int64_t g = mine * 8 + j;
-                if (g >= g0 && g < g1) {
+                const int rel = rel0 + j;
+                if ((unsigned)rel < (unsigned)wlen) {
                     const int y_num = Z[j] + bias_i;
                     need_literal |= y_num < guard;
                     const float y32 = (float)((double)y_num * sg.rden);
                     const double sgn = positive ? ((double)y32 - baseline) : (baseline - (double)y32);
-                    acc.add(sgn, (int)(g - off));
+                    if (y_order) {
+                        const bool better = positive ? (y32 > ext_y) : (y32 < ext_y);  // ascending rel: first kept
+                        ext_y = better ? y32 : ext_y;
+                        ext_i = better ? ilo + rel : ext_i;
+                        acc.sum += sgn > 0.0 ? sgn : 0.0;
+                    } else {
+                        acc.add(sgn, ilo + rel);
+                    }
                 }
             }
         }
+    }
+    if (y_order && ext_i != 0x7fffffff) {
+        acc.best = positive ? ((double)ext_y - baseline) : (baseline - (double)ext_y);
+        acc.best_i = ext_i;
     }
     if (__ballot(work && (seg_start < H || seg_end > L - H)) != 0) {
         if (work && (seg_start < H || seg_end > L - H)) {
