@@ -38,7 +38,7 @@ from waveformanalysis_amd import synth  # noqa: E402
 from waveformanalysis_amd.device import DeviceSession  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FUSED_KERNEL = "k_hits<sg_fused,baseline>"
+FUSED_KERNEL = "k_sg_mask_span<baseline>"  # dominant kernel of the fused pass (uniform-length records)
 
 
 def cpu_baseline(records: np.ndarray, pool: np.ndarray, n_records: int) -> dict:
@@ -72,9 +72,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preset", default="v1725")
     ap.add_argument("--records", type=int, default=1_250_000, help="records per GPU (x800 = 1e9 samples)")
-    ap.add_argument("--cpu-records", type=int, default=12_500, help="records in the CPU baseline slice")
+    ap.add_argument("--cpu-records", type=int, default=125_000, help="records in the CPU baseline slice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threshold", type=float, default=10.0, help="hit threshold (reference default 10.0)")
+    ap.add_argument("--no-features", action="store_true", help="skip the untimed feature / filter kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,10 +159,23 @@ def main() -> None:
         if rank == 0:
             assert rows is not None and len(rows) == total_hits
 
+    # ---- the other per-record kernels of the path, timed once each (not part of the metric) ----------
+    extra_ms = {}
+    if rank == 0 and not args.no_features:
+        from waveformanalysis_amd import _lib as L_
+
+        sess.profile(True)
+        sess.basic_features(L_.SRC_RAW)
+        sess.width_integral(L_.SRC_RAW, dt=4.0)
+        sess.savgol(download=False)
+        extra_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in sess.profile_report().items()}
+        sess.profile(False)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_samples * n_gpus / (elapsed / args.steps) / 1e9
-        k_ms, k_n = prof.get(FUSED_KERNEL, (0.0, 0))
+        kname = FUSED_KERNEL if FUSED_KERNEL in prof else max(prof, key=lambda k: prof[k][0])
+        k_ms, k_n = prof.get(kname, (0.0, 0))
         k_avg_s = (k_ms / k_n) * 1e-3 if k_n else float("nan")
         algo_bytes = 2 * n_samples + 29 * len(records) + 60 * n_hits
         achieved = algo_bytes / k_avg_s / 1e9 if k_n else float("nan")
@@ -169,7 +183,7 @@ def main() -> None:
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(FUSED_KERNEL)
+                traffic = json.load(open(tpath)).get(kname)
             except Exception:
                 traffic = None
         out = {
@@ -201,11 +215,12 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": FUSED_KERNEL,
+                "kernel": kname,
                 "kernel_avg_ms": round(k_avg_s * 1e3, 4),
                 "algorithmic_bytes": algo_bytes,
             },
             "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
+            "other_kernels_ms": extra_ms,
             "setup": {"generate_s": round(gen_s, 2), "h2d_s": round(h2d_s, 3),
                       "h2d_GBps": round((2 * n_samples) / h2d_s / 1e9, 2)},
         }

@@ -105,7 +105,7 @@ def test_basic_features(sess, name):
             sess.upload_filtered_pool(case[pool])
         sess.upload_records(case["records"])
         got = sess.basic_features(src, bp["height_range"], bp["area_range"], fixed)
-        G.assert_struct_equal(got, case[key], float_rtol=FLOAT_RTOL, float_atol=1e-4, what=f"{name} {key}")
+        G.assert_struct_equal(got, case[key], what=f"{name} {key} (bit-exact)")
 
 
 @pytest.mark.parametrize("name", G.case_names())
@@ -121,7 +121,7 @@ def test_width_integral(sess, name):
             sess.upload_filtered_pool(case[pool])
         sess.upload_records(case["records"])
         got = sess.width_integral(src, wp["q_low"], wp["q_high"], float(dt))
-        G.assert_struct_equal(got, case[key], float_rtol=FLOAT_RTOL, what=f"{name} {key}")
+        G.assert_struct_equal(got, case[key], what=f"{name} {key} (bit-exact)")
 
 
 def test_against_oracle_medium(sess):
@@ -138,10 +138,11 @@ def test_against_oracle_medium(sess):
     want = O.threshold_hits_chunked(rec, want_filt)
     G.assert_struct_equal(sess.threshold_hits(_lib.SRC_F32), want, float_rtol=FLOAT_RTOL, what="f32 hits")
     G.assert_struct_equal(sess.threshold_hits(_lib.SRC_SG_FUSED), want, float_rtol=FLOAT_RTOL, what="fused hits")
-    G.assert_struct_equal(sess.basic_features(_lib.SRC_RAW), O.basic_features(rec, pool),
-                          float_rtol=FLOAT_RTOL, float_atol=1e-4, what="bf")
-    G.assert_struct_equal(sess.width_integral(_lib.SRC_RAW, dt=2.0), O.width_integral(rec, pool),
-                          float_rtol=FLOAT_RTOL, what="wi")
+    # features reproduce numpy's summation order: bit-exact floats, raw and filtered pools
+    G.assert_struct_equal(sess.basic_features(_lib.SRC_RAW), O.basic_features(rec, pool), what="bf raw")
+    G.assert_struct_equal(sess.width_integral(_lib.SRC_RAW, dt=2.0), O.width_integral(rec, pool), what="wi raw")
+    G.assert_struct_equal(sess.basic_features(_lib.SRC_F32), O.basic_features(rec, want_filt), what="bf filt")
+    G.assert_struct_equal(sess.width_integral(_lib.SRC_F32, dt=2.0), O.width_integral(rec, want_filt), what="wi filt")
 
 
 def test_plugins_drop_in_chain():
@@ -156,8 +157,8 @@ def test_plugins_drop_in_chain():
     )
     np.testing.assert_array_equal(ctx.get_data("run", "wave_pool_filtered"), case["wave_pool_filtered"])
     G.assert_struct_equal(ctx.get_data("run", "hit_threshold"), case["hits_filt"], float_rtol=FLOAT_RTOL)
-    G.assert_struct_equal(ctx.get_data("run", "basic_features"), case["bf_raw"], float_rtol=FLOAT_RTOL, float_atol=1e-4)
-    G.assert_struct_equal(ctx.get_data("run", "waveform_width_integral"), case["wi_raw"], float_rtol=FLOAT_RTOL)
+    G.assert_struct_equal(ctx.get_data("run", "basic_features"), case["bf_raw"])
+    G.assert_struct_equal(ctx.get_data("run", "waveform_width_integral"), case["wi_raw"])
     # fused variant gives the same hits without materialising the filtered pool
     ctx2 = SimpleContext({"hit_threshold": {**opt["hit"], "use_filtered": True, "fuse_filter": True}},
                          {"records": case["records"], "wave_pool": case["wave_pool"]},
@@ -178,3 +179,33 @@ def test_error_behaviour(sess):
     with pytest.raises(ValueError, match="q_low/q_high"):
         sess.upload_records(case["records"])
         sess.width_integral(_lib.SRC_RAW, 0.9, 0.1, 1.0)
+
+
+def test_features_long_and_positive_records(sess):
+    """Records longer than numpy's 8192-element reduce buffer and known polarities (float32 signal path)."""
+    rng = np.random.default_rng(11)
+    lens = [20000, 8193, 8192, 129, 128, 127, 9, 8, 7, 1]
+    rec = np.zeros(len(lens), dtype=O.RECORDS_DTYPE)
+    parts, cur = [], 3
+    parts.append(np.zeros(3, dtype=np.uint16))
+    for i, L in enumerate(lens):
+        w = np.clip(np.rint(8000 + rng.normal(0, 40, L)), 0, 65535).astype(np.uint16)
+        w[L // 3 : L // 3 + max(L // 10, 1)] -= 300
+        rec["wave_offset"][i], rec["event_length"][i] = cur, L
+        rec["baseline"][i] = float(np.mean(w[: min(40, L)].astype(float)))
+        parts.append(w)
+        cur += L
+    rec["record_id"] = np.arange(len(lens))
+    rec["dt"] = 2
+    rec["timestamp"] = np.arange(len(lens)) * 10**8
+    rec["polarity"] = ["unknown", "negative", "positive", "unknown", "negative", "positive", "unknown", "negative",
+                       "positive", "unknown"]
+    pool = np.concatenate(parts)
+    sess.upload_pool(pool)
+    sess.upload_records(rec)
+    G.assert_struct_equal(sess.basic_features(_lib.SRC_RAW, (40, 90), (0, None)),
+                          O.basic_features(rec, pool), what="bf long")
+    G.assert_struct_equal(sess.basic_features(_lib.SRC_RAW, (-50, None), (5, -3)),
+                          O.basic_features(rec, pool, height_range=(-50, None), area_range=(5, -3)), what="bf slices")
+    G.assert_struct_equal(sess.width_integral(_lib.SRC_RAW, 0.1, 0.9, 2.0), O.width_integral(rec, pool, dt=2.0),
+                          what="wi long")

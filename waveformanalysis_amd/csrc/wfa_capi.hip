@@ -549,9 +549,20 @@ int wfa_savgol(wfa_ctx* c, float* out) {
     WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
     if (c->R > 0) {
         PoolView pv = pool_view(c);
+        const SgParams sp0 = sg_params(c);
         LaunchTimer t(c);
-        WFA_HIP_CHECK(launch_savgol(c->stream, pv, rec_view(c), sg_params(c), c->pool_f32.as<float>()));
-        if ((rc = t.end("k_savgol"))) return rc;
+        if (c->span_ok && c->span_L >= 16 && c->span_L >= sp0.W && sg_mask_supported(sp0) &&
+            !getenv("WFA_DISABLE_FAST")) {
+            SpanParams sp{};
+            sp.off0 = c->span_off0; sp.L = c->span_L; sp.positive = 0;
+            sp.rs = 64;
+            sp.n_spans = (c->R + sp.rs - 1) / sp.rs;
+            WFA_HIP_CHECK(launch_savgol_span(c->stream, pv, rec_view(c), sp0, sp, c->pool_f32.as<float>()));
+            if ((rc = t.end("k_savgol_span"))) return rc;
+        } else {
+            WFA_HIP_CHECK(launch_savgol(c->stream, pv, rec_view(c), sp0, c->pool_f32.as<float>()));
+            if ((rc = t.end("k_savgol"))) return rc;
+        }
     }
     c->have_f32 = true;
     if (out)
@@ -590,6 +601,8 @@ int wfa_basic_features(wfa_ctx* c, int source, int64_t h0, int64_t h1, int h_has
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = need_source(c, source))) return rc;
+    if (source == WFA_SRC_SG_FUSED)
+        return fail(WFA_E_INVALID, "basic_features reads wave_pool or a materialised wave_pool_filtered");
     if (c->R == 0) return WFA_OK;
     if (!out_rows) return fail(WFA_E_INVALID, "out_rows is null");
     FeatParams fp{};
@@ -616,6 +629,8 @@ int wfa_width_integral(wfa_ctx* c, int source, double q_low, double q_high, doub
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = need_source(c, source))) return rc;
+    if (source == WFA_SRC_SG_FUSED)
+        return fail(WFA_E_INVALID, "width_integral reads wave_pool or a materialised wave_pool_filtered");
     if (!(q_low > 0.0) || !(q_high < 1.0) || !(q_low < q_high))  // waveform_width_integral.py:95-96
         return fail(WFA_E_INVALID, "q_low/q_high invalid: q_low=%g, q_high=%g", q_low, q_high);
     if (c->R == 0) return WFA_OK;

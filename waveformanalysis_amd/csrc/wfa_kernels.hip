@@ -981,6 +981,161 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
     }
 }
 
+// ---- K2 (span mode): materialised wave_pool_filtered from exact integer numerators ---------------------
+// Same tiling as k_sg_mask_span; every lane turns its 8 numerators into float32 with
+// y = f32(f64(n.x) * (1/den)) (equal to scipy's float32 output for |n.x| >= guard) and
+// stores 32 contiguous bytes.  Numerators below the guard and the 2H edge samples of every record
+// (integer projection rows, literal below their guard) use the float64 code of k_savgol.
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView rec, SgParams sg, SpanParams sp,
+                                                        float* __restrict__ out) {
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    __shared__ float s_edge[kWavesPerBlock][kWave][2 * H];
+    __shared__ int32_t etab[2 * H * W];
+    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
+    __syncthreads();
+    const int lane = lane_id();
+    const int wv = wave_in_block();
+    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int L = sp.L;
+    uint32_t cpm[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        const int n0 = sg.itab[2 * m];
+        const int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
+        cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+    }
+    const int bias_i = 32768 * sg.den;
+    const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
+    const int64_t guard_e = sg.guard_edge;
+    const uint32_t fillb = 0x80008000u;
+
+    for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
+        const int64_t r0 = span * sp.rs;
+        const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
+        const int64_t g_base = sp.off0 + r0 * L;
+        // ---- edges: lane = record ----
+        if (lane < nrec) {
+            const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * L) >> 3);
+            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * L, L);
+#pragma unroll 1
+            for (int side = 0; side < 2; ++side) {
+                const uint4 c0 = side == 0 ? p[0] : p[(L >> 3) - 2];
+                const uint4 c1 = side == 0 ? p[1] : p[(L >> 3) - 1];
+                const uint32_t dw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                int xw[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int q0 = k, q1 = 16 - W + k;
+                    const uint32_t lo = (dw[q0 >> 1] >> (16 * (q0 & 1))) & 0xffffu;
+                    const uint32_t hi = (dw[q1 >> 1] >> (16 * (q1 & 1))) & 0xffffu;
+                    xw[k] = (int)(side == 0 ? lo : hi);
+                }
+#pragma unroll 1
+                for (int eh = 0; eh < H; ++eh) {
+                    const int e = side * H + eh;
+                    int acc = 0;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) acc += etab[e * W + k] * xw[k];
+                    float y;
+                    if ((int64_t)acc >= guard_e) y = (float)((double)acc * sg.rden_edge);
+                    else y = sg_value_f64(src.xu, L, side == 0 ? eh : L - H + eh, src.sg);
+                    s_edge[wv][lane][e] = y;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        const int span_samples = nrec * L;
+        const int T = (span_samples + 511) / 512;
+        const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
+        float* __restrict__ out_span = out + g_base;
+        const int last_chunk_pos = span_samples - 8;
+        auto tile_at = [&](int t) {
+            int pos = t * 512 + lane * 8;
+            pos = pos < last_chunk_pos ? pos : last_chunk_pos;
+            const uint4 v = *reinterpret_cast<const uint4*>(span_ptr + pos);
+            Tile x;
+            x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
+            return x;
+        };
+        int rl = (lane * 8) / L;
+        int i0 = lane * 8 - rl * L;
+        uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;
+        auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
+            const int pos = t * 512 + lane * 8;
+            const bool in_span = pos < span_samples;
+            uint32_t E[12];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) E[4 + k] = cur.d[k] ^ 0x80008000u;
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80008000u;
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80008000u;
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80008000u;
+            const uint32_t n3 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[3], 0) ^ 0x80008000u;
+            E[0] = dpp_from_prev_lane(p0, E[4]);
+            E[1] = dpp_from_prev_lane(p1, E[5]);
+            E[2] = dpp_from_prev_lane(p2, E[6]);
+            E[3] = dpp_from_prev_lane(p3, E[7]);
+            E[8] = dpp_from_next_lane(n0, E[4]);
+            E[9] = dpp_from_next_lane(n1, E[5]);
+            E[10] = dpp_from_next_lane(n2, E[6]);
+            E[11] = dpp_from_next_lane(n3, E[7]);
+            int Z[8];
+            sg_chunk_numerators<W>(E, cpm, Z);
+            float y[8];
+            bool low = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int y_num = Z[j] + bias_i;
+                low |= y_num < guard;
+                y[j] = (float)((double)y_num * sg.rden);
+            }
+            const bool first = i0 == 0, last = i0 == L - 8;
+            if (__ballot(in_span && (low || first || last)) != 0) {
+                if (in_span && low) {  // below the integer guard: scipy's float64 chain, literally
+                    WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rl * L, L);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (Z[j] + bias_i < guard && i0 + j >= H && i0 + j < L - H) y[j] = sg_value_f64(src.xu, L, i0 + j, src.sg);
+                }
+                if (in_span && first) {
+#pragma unroll
+                    for (int j = 0; j < H; ++j) y[j] = s_edge[wv][rl][j];
+                }
+                if (in_span && last) {
+#pragma unroll
+                    for (int j = 0; j < H; ++j) y[8 - H + j] = s_edge[wv][rl][H + j];
+                }
+            }
+            if (in_span) {
+                float4* dst = reinterpret_cast<float4*>(out_span + pos);
+                dst[0] = make_float4(y[0], y[1], y[2], y[3]);
+                dst[1] = make_float4(y[4], y[5], y[6], y[7]);
+            }
+            p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
+            p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
+            p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
+            p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
+            i0 += 512;
+            while (i0 >= L) { i0 -= L; ++rl; }
+        };
+        Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
+        int t = 0;
+        for (; t + 4 <= T; t += 4) {
+            rd = tile_at(t + 3); do_tile(t, ra, rb);
+            ra = tile_at(t + 4); do_tile(t + 1, rb, rc);
+            rb = tile_at(t + 5); do_tile(t + 2, rc, rd);
+            rc = tile_at(t + 6); do_tile(t + 3, rd, ra);
+        }
+        if (t < T) { rd = tile_at(t + 3); do_tile(t, ra, rb); ++t; }
+        if (t < T) { do_tile(t, rb, rc); ++t; }
+        if (t < T) { do_tile(t, rc, rd); ++t; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // ---- A (span mode, matrix cores): the FIR as a banded matrix product -----------------------------------
 // Same contract as k_sg_mask_span, for L % 32 == 0 and |n_k| <= 127.  Measured: the integer VALU issues
 // one wave64 op per ~4.2 cycles (tools/valu_rate.hip), so 48 dot2 + 9 perm per tile make the dot2 kernel
@@ -1566,8 +1721,106 @@ __global__ __launch_bounds__(kBlock) void k_hits_gather(const uint8_t* __restric
 }
 
 // =============================================================================================
-// K5: basic features  (basic_features.py:108-195)
+// K5 / K6: per-record features, one lane per record, sequential semantics
 // =============================================================================================
+// The reference computes these with numpy reductions whose float64 rounding depends on the order of
+// the additions.  One lane walks its record in sample order and performs literally the same sequence:
+//   np.sum      = sum over 8192-element blocks of numpy's pairwise sum (128-element leaves with 8
+//                 interleaved accumulators, halves split at multiples of 8)         -> `Pairwise`
+//   np.cumsum   = strictly sequential                                               -> running sum
+//   np.searchsorted(side="left") = first index with cumsum >= target
+// so area / q_total / the quantile indices are bit-identical, not merely within tolerance.
+// Loads are 16-byte chunks per lane (records of neighbouring lanes are apart, lines are reused from
+// L1/L2 over the next chunks).
+
+constexpr int kFeatBlock = 128;  // threads per block (LDS stacks are per thread)
+
+struct PairwiseStacks {
+    int w[24][kFeatBlock];     // work stack: pending sub-array lengths, -1 = combine marker
+    double v[12][kFeatBlock];  // value stack
+};
+
+struct Pairwise {
+    double R[8];
+    double res, total;
+    int rot, cur_len, k, n_left, wsp, vsp;
+    PairwiseStacks* st;
+    int tid;
+
+    __device__ __forceinline__ void advance() {
+        for (;;) {
+            if (wsp == 0) {
+                if (vsp > 0) { total += st->v[0][tid]; vsp = 0; }  // block done: total += pairwise(block)
+                if (n_left == 0) { cur_len = 0; return; }
+                const int blk = n_left < 8192 ? n_left : 8192;       // numpy's reduce buffer
+                n_left -= blk;
+                st->w[wsp++][tid] = blk;
+            }
+            const int x = st->w[--wsp][tid];
+            if (x < 0) {
+                const double bb = st->v[--vsp][tid];
+                const double aa = st->v[--vsp][tid];
+                st->v[vsp++][tid] = aa + bb;
+                continue;
+            }
+            if (x > 128) {
+                int n2 = x / 2;
+                n2 -= n2 % 8;
+                st->w[wsp++][tid] = -1;
+                st->w[wsp++][tid] = x - n2;
+                st->w[wsp++][tid] = n2;
+                continue;
+            }
+            cur_len = x;
+            k = 0;
+            return;
+        }
+    }
+    __device__ __forceinline__ void init(int n, int rot_, PairwiseStacks* stacks, int tid_) {
+        st = stacks; tid = tid_; rot = rot_ & 7;
+        total = 0.0; res = 0.0; n_left = n > 0 ? n : 0; wsp = 0; vsp = 0; cur_len = 0; k = 0;
+        advance();
+    }
+    // r[j] = R[(j + rot) & 7]; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+    __device__ __forceinline__ double tree() const {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = R[j];
+        if (rot & 1) { const double x0 = t[0];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) t[j] = t[j + 1];
+            t[7] = x0; }
+        if (rot & 2) { const double x0 = t[0], x1 = t[1];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) t[j] = t[j + 2];
+            t[6] = x0; t[7] = x1; }
+        if (rot & 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double x = t[j]; t[j] = t[j + 4]; t[j + 4] = x; }
+        }
+        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    // next element of the array; JJ = (its index + rot) & 7, a compile-time chunk position
+    template <int JJ>
+    __device__ __forceinline__ void feed(double a) {
+        if (cur_len < 8) {
+            res = (k == 0 ? 0.0 : res) + a;
+        } else {
+            const int m = cur_len & ~7;
+            if (k < 8) R[JJ] = a;
+            else if (k < m) R[JJ] += a;
+            else { if (k == m) res = tree(); res += a; }
+        }
+        ++k;
+        if (k == cur_len) {
+            if (cur_len >= 8 && (cur_len & 7) == 0) res = tree();
+            st->v[vsp++][tid] = res;
+            advance();
+        }
+    }
+    __device__ __forceinline__ double result() const { return total; }  // 0.0 + block sums, in order
+};
+
 __device__ __forceinline__ void py_slice(int64_t start, int64_t end, int has_end, int L, int& lo,
                                          int& hi) {
     int64_t s = start;
@@ -1578,153 +1831,177 @@ __device__ __forceinline__ void py_slice(int64_t start, int64_t end, int has_end
     hi = (int)(e < s ? s : e);
 }
 
+// 8 wave values of the aligned chunk c (pool samples 8c..8c+7) as float64 and float32
 template <int SRC>
-__global__ __launch_bounds__(kBlock) void k_basic_features(PoolView pool, RecView rec, SgParams sg,
-                                                           FeatParams fp, uint8_t* __restrict__ out) {
-    const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-    const double inf = __builtin_huge_val();
-    for (int64_t r = wave0; r < rec.R; r += nwaves) {
-        const int L = rec.len[r];
-        const int64_t off = rec.off[r];
-        WaveSrc<SRC> src = make_src<SRC>(pool, sg, off, L);
-        double baseline = rec.baseline[r];
-        if (fp.fixed_bl) {
-            const double fb = fp.fixed_bl[r];
-            if (fb == fb) baseline = fb;  // basic_features.py:143-146
-        }
-        const int pol = rec.pol[r];
-        const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
-        int p0, p1, c0, c1;
-        py_slice(fp.h0, fp.h1, fp.h_has_end, L, p0, p1);
-        py_slice(fp.a0, fp.a1, fp.a_has_end, L, c0, c1);
-
-        double vmin = inf, vmax = -inf, area = 0.0, mad = 0.0;
-        if (known) {
-            // s = -rv.signals(id, baseline): float32 arithmetic (records_view.py:87-100)
-            const float b32 = (float)baseline;
-            for (int i = lane; i < L; i += kWave) {
-                const float d = src.at_f32(i) - b32;
-                const double s = (double)(pol == WFA_POL_POSITIVE ? d : -d);
-                if (i >= p0 && i < p1) { vmin = fmin(vmin, s); vmax = fmax(vmax, s); }
-                if (i >= c0 && i < c1) area += s;
-            }
-        } else {
-            for (int i = lane; i < L; i += kWave) {
-                const double w = src.at(i);
-                if (i >= p0 && i < p1) { vmin = fmin(vmin, w); vmax = fmax(vmax, w); }
-                if (i >= c0 && i < c1) area += baseline - w;  // effective polarity "negative"
-            }
-        }
-        // max |diff| over the whole record on the wave values (basic_features.py:187-189)
-        for (int i = lane; i + 1 < L; i += kWave) {
-            const double d = src.at(i + 1) - src.at(i);
-            mad = fmax(mad, fabs(d));
-        }
-        vmin = wave_min(vmin); vmax = wave_max(vmax); area = wave_sum(area); mad = wave_max(mad);
-
-        if (lane == 0) {
-            float height = 0.f, amp = 0.f, area_f = 0.f, mad_f = 0.f;
-            if (p1 > p0) {
-                height = known ? (float)vmax : (float)(baseline - vmin);
-                amp = (float)(vmax - vmin);
-            }
-            if (c1 > c0) area_f = (float)area;
-            if (L > 1) mad_f = (float)mad;
-            uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 36);
-            put_f32(row, 0, height);
-            put_f32(row, 1, amp);
-            put_f32(row, 2, area_f);
-            put_f32(row, 3, mad_f);
-            put_i64(row, 4, rec.ts[r]);
-            row[6] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
-            put_i64(row, 7, r);
-        }
-    }
-}
-
-// =============================================================================================
-// K6: integral-quantile width  (waveform_width_integral.py:166-227)
-// =============================================================================================
-template <int SRC>
-__device__ __forceinline__ double width_x(const WaveSrc<SRC>& src, int i, bool known, int pol,
-                                          float b32, double baseline) {
-    double s;
-    if (known) {
-        const float d = src.at_f32(i) - b32;
-        s = (double)(pol == WFA_POL_POSITIVE ? d : -d);
-    } else {
-        s = -(src.at(i) - baseline);
-    }
-    return s > 0.0 ? s : 0.0;
-}
-
-template <int SRC>
-__global__ __launch_bounds__(kBlock) void k_width_integral(PoolView pool, RecView rec, SgParams sg,
-                                                           WidthParams wp, uint8_t* __restrict__ out) {
-    const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-    for (int64_t r = wave0; r < rec.R; r += nwaves) {
-        const int L = rec.len[r];
-        const int64_t off = rec.off[r];
-        WaveSrc<SRC> src = make_src<SRC>(pool, sg, off, L);
-        const double baseline = rec.baseline[r];
-        const float b32 = (float)baseline;
-        const int pol = rec.pol[r];
-        const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
-
-        double q = 0.0;
-        for (int i = lane; i < L; i += kWave) q += width_x<SRC>(src, i, known, pol, b32, baseline);
-        q = wave_sum(q);
-
-        int lo_i = 0, hi_i = 0;
-        const bool ok = q > 0.0 && q <= 1.7976931348623157e308;  // finite and positive
-        if (ok) {
-            const double t_lo = wp.q_low * q, t_hi = wp.q_high * q;
-            lo_i = -1; hi_i = -1;
-            double carry = 0.0;
-            for (int base = 0; base < L && (lo_i < 0 || hi_i < 0); base += kWave) {
-                const int i = base + lane;
-                const double x = i < L ? width_x<SRC>(src, i, known, pol, b32, baseline) : 0.0;
-                double inc = x;
+__device__ __forceinline__ void load_chunk(const PoolView& pool, int64_t c, double (&wd)[8], float (&wf)[8]) {
+    if (SRC == WFA_SRC_RAW) {
+        const uint4 v = reinterpret_cast<const uint4*>(pool.u16)[c];
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int d = 1; d < kWave; d <<= 1) {
-                    const double o = __shfl_up(inc, d, kWave);
-                    if (lane >= d) inc += o;
-                }
-                const double c = carry + inc;
-                const bool valid = i < L;
-                if (lo_i < 0) {
-                    const uint64_t m = __ballot(valid && c >= t_lo);
-                    if (m) lo_i = base + __ffsll((long long)m) - 1;
-                }
-                if (hi_i < 0) {
-                    const uint64_t m = __ballot(valid && c >= t_hi);
-                    if (m) hi_i = base + __ffsll((long long)m) - 1;
-                }
-                carry = __shfl(c, kWave - 1, kWave);
-            }
-            if (lo_i < 0) lo_i = L;  // np.searchsorted returns len(cumsum)
-            if (hi_i < 0) hi_i = L;
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t x = (d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            wf[j] = (float)x;
+            wd[j] = (double)x;
         }
-        if (lane == 0) {
-            const double lo = (double)lo_i, hi = (double)hi_i;
-            const double w = (double)(hi_i - lo_i > 0 ? hi_i - lo_i : 0);
-            uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 52);
-            put_f32(row, 0, (float)(lo * wp.dt));
-            put_f32(row, 1, (float)(hi * wp.dt));
-            put_f32(row, 2, (float)(w * wp.dt));
-            put_f32(row, 3, (float)lo);
-            put_f32(row, 4, (float)hi);
-            put_f32(row, 5, (float)w);
-            put_f64(row, 6, q);
-            put_i64(row, 8, rec.ts[r]);
-            row[10] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
-            put_i64(row, 11, r);
+    } else {
+        const float4 v0 = reinterpret_cast<const float4*>(pool.f32)[2 * c];
+        const float4 v1 = reinterpret_cast<const float4*>(pool.f32)[2 * c + 1];
+        const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wf[j] = f[j]; wd[j] = (double)f[j]; }
+    }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kFeatBlock) void k_basic_features(PoolView pool, RecView rec, FeatParams fp,
+                                                               uint8_t* __restrict__ out) {
+    __shared__ PairwiseStacks stacks;
+    const int64_t r = (int64_t)blockIdx.x * kFeatBlock + threadIdx.x;
+    if (r >= rec.R) return;
+    const int L = rec.len[r];
+    const int64_t off = rec.off[r];
+    double baseline = rec.baseline[r];
+    if (fp.fixed_bl) {
+        const double fb = fp.fixed_bl[r];
+        if (fb == fb) baseline = fb;  // basic_features.py:143-146
+    }
+    const int pol = rec.pol[r];
+    const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
+    const float b32 = (float)baseline;
+    int p0, p1, c0, c1;
+    py_slice(fp.h0, fp.h1, fp.h_has_end, L, p0, p1);
+    py_slice(fp.a0, fp.a1, fp.a_has_end, L, c0, c1);
+
+    Pairwise pw;
+    pw.init(c1 - c0, (int)((off + c0) & 7), &stacks, threadIdx.x);
+    const double inf = __builtin_huge_val();
+    double vmin = inf, vmax = -inf, mad = 0.0, prev = 0.0;
+    if (L > 0) {
+        const int64_t c_lo = off >> 3, c_hi = (off + L - 1) >> 3;
+        for (int64_t c = c_lo; c <= c_hi; ++c) {
+            double wd[8];
+            float wf[8];
+            load_chunk<SRC>(pool, c, wd, wf);
+            const int ib = (int)(c * 8 - off);
+#define WFA_BF_STEP(JJ)                                                                              \
+            {                                                                                        \
+                const int i = ib + JJ;                                                               \
+                if (i >= 0 && i < L) {                                                               \
+                    double val, term;                                                                \
+                    if (known) { /* s = -rv.signals(id, baseline): float32 (records_view.py:87-100) */ \
+                        const float dd = wf[JJ] - b32;                                               \
+                        val = (double)(pol == WFA_POL_POSITIVE ? dd : -dd);                          \
+                        term = val;                                                                  \
+                    } else {                                                                         \
+                        val = wd[JJ];                                                                \
+                        term = baseline - wd[JJ]; /* effective polarity "negative" */                \
+                    }                                                                                \
+                    if (i >= p0 && i < p1) { vmin = val < vmin ? val : vmin; vmax = val > vmax ? val : vmax; } \
+                    if (i >= c0 && i < c1) pw.feed<JJ>(term);                                        \
+                    if (i > 0) { const double dv = fabs(wd[JJ] - prev); mad = dv > mad ? dv : mad; } \
+                    prev = wd[JJ];                                                                   \
+                }                                                                                    \
+            }
+            WFA_BF_STEP(0) WFA_BF_STEP(1) WFA_BF_STEP(2) WFA_BF_STEP(3)
+            WFA_BF_STEP(4) WFA_BF_STEP(5) WFA_BF_STEP(6) WFA_BF_STEP(7)
+#undef WFA_BF_STEP
         }
     }
+    float height = 0.f, amp = 0.f, area_f = 0.f, mad_f = 0.f;
+    if (p1 > p0) {
+        height = known ? (float)vmax : (float)(baseline - vmin);
+        amp = (float)(vmax - vmin);
+    }
+    if (c1 > c0) area_f = (float)pw.result();
+    if (L > 1) mad_f = (float)mad;
+    uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 36);
+    put_f32(row, 0, height);
+    put_f32(row, 1, amp);
+    put_f32(row, 2, area_f);
+    put_f32(row, 3, mad_f);
+    put_i64(row, 4, rec.ts[r]);
+    row[6] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
+    put_i64(row, 7, r);
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, RecView rec, WidthParams wp,
+                                                               uint8_t* __restrict__ out) {
+    __shared__ PairwiseStacks stacks;
+    const int64_t r = (int64_t)blockIdx.x * kFeatBlock + threadIdx.x;
+    if (r >= rec.R) return;
+    const int L = rec.len[r];
+    const int64_t off = rec.off[r];
+    const double baseline = rec.baseline[r];
+    const float b32 = (float)baseline;
+    const int pol = rec.pol[r];
+    const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
+    const int64_t c_lo = off >> 3, c_hi = (off + L - 1) >> 3;
+
+    // x_i = max(signal_i, 0)   (waveform_width_integral.py:180-190)
+    auto xval = [&](double wdj, float wfj) {
+        double sgl;
+        if (known) {
+            const float dd = wfj - b32;
+            sgl = (double)(pol == WFA_POL_POSITIVE ? dd : -dd);
+        } else {
+            sgl = -(wdj - baseline);
+        }
+        return sgl > 0.0 ? sgl : 0.0;
+    };
+
+    Pairwise pw;
+    pw.init(L, (int)(off & 7), &stacks, threadIdx.x);
+    if (L > 0) {
+        for (int64_t c = c_lo; c <= c_hi; ++c) {
+            double wd[8];
+            float wf[8];
+            load_chunk<SRC>(pool, c, wd, wf);
+            const int ib = (int)(c * 8 - off);
+#define WFA_WI_SUM(JJ) { const int i = ib + JJ; if (i >= 0 && i < L) pw.feed<JJ>(xval(wd[JJ], wf[JJ])); }
+            WFA_WI_SUM(0) WFA_WI_SUM(1) WFA_WI_SUM(2) WFA_WI_SUM(3) WFA_WI_SUM(4) WFA_WI_SUM(5) WFA_WI_SUM(6) WFA_WI_SUM(7)
+#undef WFA_WI_SUM
+        }
+    }
+    const double q = pw.result();
+
+    int lo_i = 0, hi_i = 0;
+    const bool ok = q > 0.0 && q <= 1.7976931348623157e308;  // finite and positive
+    if (ok) {
+        const double t_lo = wp.q_low * q, t_hi = wp.q_high * q;
+        lo_i = -1; hi_i = -1;
+        double cs = 0.0;  // np.cumsum: sequential
+        for (int64_t c = c_lo; c <= c_hi && hi_i < 0; ++c) {
+            double wd[8];
+            float wf[8];
+            load_chunk<SRC>(pool, c, wd, wf);
+            const int ib = (int)(c * 8 - off);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int i = ib + jj;
+                if (i >= 0 && i < L) {
+                    cs += xval(wd[jj], wf[jj]);
+                    if (lo_i < 0 && cs >= t_lo) lo_i = i;
+                    if (hi_i < 0 && cs >= t_hi) hi_i = i;
+                }
+            }
+        }
+        if (lo_i < 0) lo_i = L;  // np.searchsorted returns len(cumsum)
+        if (hi_i < 0) hi_i = L;
+    }
+    const double lo = (double)lo_i, hi = (double)hi_i;
+    const double w = (double)(hi_i - lo_i > 0 ? hi_i - lo_i : 0);
+    uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 52);
+    put_f32(row, 0, (float)(lo * wp.dt));
+    put_f32(row, 1, (float)(hi * wp.dt));
+    put_f32(row, 2, (float)(w * wp.dt));
+    put_f32(row, 3, (float)lo);
+    put_f32(row, 4, (float)hi);
+    put_f32(row, 5, (float)w);
+    put_f64(row, 6, q);
+    put_i64(row, 8, rec.ts[r]);
+    row[10] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
+    put_i64(row, 11, r);
 }
 
 // =============================================================================================
@@ -1795,25 +2072,29 @@ hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t*
 
 hipError_t launch_basic_features(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const FeatParams& fp, uint8_t* out) {
-    const int grid = grid_for_records(rec.R);
+    (void)sg;
+    if (rec.R == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((rec.R + kFeatBlock - 1) / kFeatBlock);
     if (source == WFA_SRC_RAW)
-        hipLaunchKernelGGL((k_basic_features<WFA_SRC_RAW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, fp, out);
+        hipLaunchKernelGGL((k_basic_features<WFA_SRC_RAW>), dim3(grid), dim3(kFeatBlock), 0, st, pool, rec, fp, out);
     else if (source == WFA_SRC_F32)
-        hipLaunchKernelGGL((k_basic_features<WFA_SRC_F32>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, fp, out);
+        hipLaunchKernelGGL((k_basic_features<WFA_SRC_F32>), dim3(grid), dim3(kFeatBlock), 0, st, pool, rec, fp, out);
     else
-        hipLaunchKernelGGL((k_basic_features<WFA_SRC_SG_FUSED>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, fp, out);
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const WidthParams& wp, uint8_t* out) {
-    const int grid = grid_for_records(rec.R);
+    (void)sg;
+    if (rec.R == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((rec.R + kFeatBlock - 1) / kFeatBlock);
     if (source == WFA_SRC_RAW)
-        hipLaunchKernelGGL((k_width_integral<WFA_SRC_RAW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, wp, out);
+        hipLaunchKernelGGL((k_width_integral<WFA_SRC_RAW>), dim3(grid), dim3(kFeatBlock), 0, st, pool, rec, wp, out);
     else if (source == WFA_SRC_F32)
-        hipLaunchKernelGGL((k_width_integral<WFA_SRC_F32>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, wp, out);
+        hipLaunchKernelGGL((k_width_integral<WFA_SRC_F32>), dim3(grid), dim3(kFeatBlock), 0, st, pool, rec, wp, out);
     else
-        hipLaunchKernelGGL((k_width_integral<WFA_SRC_SG_FUSED>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, wp, out);
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1843,6 +2124,27 @@ hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, cons
     }
 #undef WFA_MASK
 #undef WFA_MASK2
+    return hipGetLastError();
+}
+
+hipError_t launch_savgol_span(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
+                              const SpanParams& sp, float* out) {
+    int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    const int grid = (int)g;
+#define WFA_SVS(WW) \
+    case WW: hipLaunchKernelGGL((k_savgol_span<WW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, sp, out); break;
+    switch (sg.W) {
+        WFA_SVS(5)
+        WFA_SVS(7)
+        WFA_SVS(9)
+        WFA_SVS(11)
+        WFA_SVS(13)
+        WFA_SVS(15)
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_SVS
     return hipGetLastError();
 }
 
