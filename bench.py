@@ -66,6 +66,12 @@ def cpu_baseline(records: np.ndarray, pool: np.ndarray, n_records: int) -> dict:
 
 
 def main() -> None:
+    # stdout carries exactly one JSON line: library banners (gloo, RCCL) are sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    from waveformanalysis_amd import _lib as _wfa_lib
+
+    _wfa_lib.load()  # bind /opt/rocm's HIP + RCCL before torch (which bundles its own copies) is imported
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -83,12 +89,13 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
-        import torch
+        # torch.distributed is control plane only (rendezvous, barrier, max over ranks, RCCL id
+        # broadcast): gloo, so torch never opens the GPU next to libwfa_hip's own HIP/RCCL runtime.
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
+    device_id = 0 if os.environ.get("WFA_BENCH_SHARE_GPU") else local_rank  # rehearsal on a 1-GPU box
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
@@ -100,7 +107,7 @@ def main() -> None:
     n_samples = int(pool.size)
     gen_s = time.perf_counter() - t0
 
-    sess = DeviceSession(local_rank)
+    sess = DeviceSession(device_id)
     t0 = time.perf_counter()
     sess.upload_pool(pool)
     rec_in = records.copy()
@@ -113,13 +120,9 @@ def main() -> None:
         return sess.fused_baseline_filter_hits((0, synth.BASELINE_SAMPLES), 2, 2, download=False)
 
     def sync_all() -> None:
-        sess.sync()
+        sess.sync()  # every launch of this rank is on the session's stream
         if dist is not None:
-            import torch
-
-            torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -137,27 +140,31 @@ def main() -> None:
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- event-grouping exchange (RCCL over xGMI), outside the timed region ---------------------------
     gather_ms = None
+    gather_note = None
     total_hits = n_hits
     if dist is not None:
         from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
 
-        uid = [DeviceSession.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        sess.rccl_init(rank, world, uid[0])
-        sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)  # warm-up (connection setup)
-        dist.barrier()
-        t0 = time.perf_counter()
-        counts, rows = sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)
-        gather_ms = (time.perf_counter() - t0) * 1e3
-        total_hits = int(counts.sum())
-        if rank == 0:
-            assert rows is not None and len(rows) == total_hits
+        try:
+            uid = [DeviceSession.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            sess.rccl_init(rank, world, uid[0])
+            sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)  # warm-up (connection setup)
+            dist.barrier()
+            t0 = time.perf_counter()
+            counts, rows = sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)
+            gather_ms = (time.perf_counter() - t0) * 1e3
+            total_hits = int(counts.sum())
+            if rank == 0:
+                assert rows is not None and len(rows) == total_hits
+        except Exception as exc:  # the exchange is reported separately; the metric does not depend on it
+            gather_note = f"RCCL gather not run: {exc}"
 
     # ---- the other per-record kernels of the path, timed once each (not part of the metric) ----------
     extra_ms = {}
@@ -227,6 +234,8 @@ def main() -> None:
         if gather_ms is not None:
             out["gather_ms"] = round(gather_ms, 3)
             out["config"]["hits_total"] = total_hits
+        if gather_note:
+            out["gather_note"] = gather_note
         if not args.no_cpu_baseline:
             n_cpu = min(args.cpu_records, len(records))
             cb = cpu_baseline(records, pool, n_cpu)
@@ -241,7 +250,8 @@ def main() -> None:
                        for f in sel.dtype.names if sel.dtype[f].kind == "f"), default=0.0) if int_ok and len(sel) else None
             out["parity"] = {"records_checked": n_cpu, "hits_checked": int(len(cpu_hits)),
                              "int_fields_bit_exact": bool(int_ok), "max_rel_err_float_fields": flt}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     sess.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -209,3 +209,57 @@ def test_features_long_and_positive_records(sess):
                           O.basic_features(rec, pool, height_range=(-50, None), area_range=(5, -3)), what="bf slices")
     G.assert_struct_equal(sess.width_integral(_lib.SRC_RAW, 0.1, 0.9, 2.0), O.width_integral(rec, pool, dt=2.0),
                           what="wi long")
+
+
+def test_sharded_equals_unsharded(sess):
+    """Channel shards processed one after the other on this GPU, merged on the host == one pass."""
+    from waveformanalysis_amd import sharding
+
+    rec, pool = synth.make_run(640, "v1725", cfg=31)
+    sess.upload_pool(pool)
+    sess.upload_records(rec, 10.0)
+    sess.set_sg_plan(11, 2)
+    want = sess.threshold_hits(_lib.SRC_SG_FUSED)
+    rows, shards = [], [sharding.make_shard(rec, pool, 4, r) for r in range(4)]
+    for s in shards:
+        sess.upload_pool(s.wave_pool)
+        sess.upload_records(s.records, 10.0)
+        rows.append(sess.threshold_hits(_lib.SRC_SG_FUSED, max_len=s.max_len))
+    merged = sharding.merge_rows(rows, [s.orig_index for s in shards], [s.records for s in shards])
+    G.assert_struct_equal(merged, want, what="sharded == unsharded")
+
+
+def test_streaming_chunks_with_device_pool():
+    """compute_chunk over a thread pool (one session / stream per worker) == the static plugin."""
+    from waveformanalysis_amd.device import DevicePool
+    from waveformanalysis_amd.streaming import HipThresholdHitStream, records_to_chunks
+
+    rec, pool = synth.make_run(3000, "v1725", cfg=32)
+    ctx = SimpleContext({}, {"records": rec, "wave_pool": pool})
+    dp = DevicePool([0])
+    try:
+        for use_filtered in (False, True):
+            plugin = HipThresholdHitStream(use_filtered=use_filtered, max_len=800, device_pool=dp)
+            chunks = records_to_chunks(rec, 700, "run")
+            outs = plugin.run_chunks(chunks, ctx, "run", max_workers=3)
+            got = np.concatenate([c.data for c in outs])
+            want = O.threshold_hits_chunked(rec, O.filter_wave_pool_uniform(pool, 800) if use_filtered else pool)
+            G.assert_struct_equal(got, want, float_rtol=FLOAT_RTOL, what=f"stream filtered={use_filtered}")
+            assert all(o.start == c.start and o.end == c.end for o, c in zip(outs, chunks))
+    finally:
+        dp.close()
+
+
+def test_rccl_single_rank_gather(sess):
+    """RCCL leg of the C ABI with a 1-rank communicator: counts all-gather + send/recv to self,
+    device-resident hit rows (rows=None) and host rows."""
+    case = G.load_case("v1725_default")
+    sess.upload_pool(case["wave_pool"])
+    sess.upload_records(case["records"], 10.0)
+    hits = sess.threshold_hits(_lib.SRC_RAW)
+    sess.rccl_init(0, 1, DeviceSession.rccl_unique_id())
+    counts, rows = sess.rccl_gather_rows(None, len(hits), hits.dtype, root=0)
+    assert counts.tolist() == [len(hits)]
+    G.assert_struct_equal(rows, hits, what="gather of resident rows")
+    counts, rows = sess.rccl_gather_rows(hits[:7], 7, hits.dtype, root=0)
+    G.assert_struct_equal(rows, hits[:7], what="gather of host rows")

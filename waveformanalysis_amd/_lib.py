@@ -77,7 +77,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(LIB_PATH)  # RTLD_LOCAL: torch ships its own HIP/RCCL copies, keep the symbol spaces apart
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = restype
