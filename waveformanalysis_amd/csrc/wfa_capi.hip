@@ -174,6 +174,9 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             if (sg_mask_mfma_supported(sp0, c->span_L) && getenv("WFA_ENABLE_MFMA")) {  // experiment, see DESIGN.md
                 WFA_HIP_CHECK(launch_sg_mask_span_mfma(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span_mfma<baseline>" : "k_sg_mask_span_mfma"))) return rc;
+            } else if (sg_mask_span16_supported(sp0, c->span_L) && !getenv("WFA_DISABLE_SPAN16")) {
+                WFA_HIP_CHECK(launch_sg_mask_span16(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+                if ((rc = t.end(fused_bl ? "k_sg_mask_span16<baseline>" : "k_sg_mask_span16"))) return rc;
             } else {
                 WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
@@ -482,33 +485,33 @@ int wfa_set_sg_plan(wfa_ctx* c, int window, int polyorder, const double* tab, co
     } else {
         if ((rc = s.itab.ensure(isz))) return rc;
     }
-    // band matrices of the matrix-core mask kernel, in MFMA operand layout:
-    // [polarity 0 (+n) / 1 (-n)][shift prev, own, next][set a, b][part P (low bytes), Q (high bytes)][lane][16]
+    // band matrices of the matrix-core mask kernel, in MFMA A-operand layout (16 x 64 int8):
+    // [polarity 0 (+n) / 1 (-n)][shift prev, own, next][part P (low bytes), Q (high bytes)][lane][16]
+    // lane = 16 g' + r holds A[row r][k = 16 g' + j]; row r = 4 g + i (k-quarter g, output i = 0..3)
     s.mfma_ok = false;
     if (int_ok && window >= 5 && window <= 15) {
         bool fits = true;
         for (int k = 0; k < window; ++k) fits = fits && itab[k] >= -127 && itab[k] <= 127;
         if (fits) {
-            std::vector<int8_t> bt((size_t)2 * 12 * 64 * 16, 0);
+            std::vector<int8_t> at((size_t)2 * 6 * 64 * 16, 0);
             const int Hh = window / 2;
             for (int pol = 0; pol < 2; ++pol)
                 for (int shift = 0; shift < 3; ++shift)
-                    for (int set = 0; set < 2; ++set)
-                        for (int part = 0; part < 2; ++part)
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int j = 0; j < 16; ++j) {
-                                    const int col = lane & 15, kq = lane >> 4;  // B[k = 16 kq + j][col]
-                                    const int want_q = 2 * set + (col >> 3);    // quarter feeding this column
-                                    const int sample = j >> 1, byte = j & 1, out = col & 7;
-                                    int v = 0;
-                                    if (kq == want_q && byte == part) {
-                                        const int tap = sample + 8 * (shift - 1) - out + Hh;
-                                        if (tap >= 0 && tap < window) v = pol ? -itab[tap] : itab[tap];
-                                    }
-                                    const size_t m = (size_t)(((pol * 3 + shift) * 2 + set) * 2 + part);
-                                    bt[(m * 64 + lane) * 16 + j] = (int8_t)v;
+                    for (int part = 0; part < 2; ++part)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 16; ++j) {
+                                const int row = lane & 15, kq = lane >> 4;
+                                const int g = row >> 2, out = row & 3;
+                                const int sample = j >> 1, byte = j & 1;
+                                int v = 0;
+                                if (kq == g && byte == part) {
+                                    const int tap = sample + 8 * (shift - 1) - out + Hh;
+                                    if (tap >= 0 && tap < window) v = pol ? -itab[tap] : itab[tap];
                                 }
-            if ((rc = h2d(c, s.mfma, bt.data(), bt.size()))) return rc;
+                                const size_t m = (size_t)((pol * 3 + shift) * 2 + part);
+                                at[(m * 64 + lane) * 16 + j] = (int8_t)v;
+                            }
+            if ((rc = h2d(c, s.mfma, at.data(), at.size()))) return rc;
             WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
             s.mfma_ok = true;
         }

@@ -411,6 +411,12 @@ typedef short wfa_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int sdot2_acc(uint32_t pair, uint32_t coef, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(wfa_s2, pair), __builtin_bit_cast(wfa_s2, coef), acc, false);
 }
+// first tap of an accumulator: VOP3P form with an inline 0 addend (hipcc otherwise emits v_mov 0 + v_dot2c)
+__device__ __forceinline__ int sdot2_first(uint32_t pair, uint32_t coef) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "v"(coef));
+    return r;
+}
 __device__ __forceinline__ uint32_t dpp_from_prev_lane(uint32_t lane0_value, uint32_t v) {
     // lane i <- lane i-1 ; lane 0 keeps lane0_value (wave_shr:1, bound_ctrl off)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);
@@ -981,6 +987,193 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolVie
     }
 }
 
+// ---- A (span mode, 16 samples per lane): same kernel with 1024-sample tiles ---------------------------
+// The dot2 kernel is VALU-issue bound (~4.2 cycles per wave64 op, tools/valu_rate.hip), and about a third
+// of its instructions are per-tile bookkeeping (halo exchange, record tracking, address math, store).
+// With two chunks per lane that part is paid once per 1024 samples.  Requires L % 16 == 0.
+template <int W>
+__device__ __forceinline__ void sg_chunk16_numerators(const uint32_t (&E)[14], const uint32_t* cpm, int (&Z)[16]) {
+    // E[0..2] = last 6 samples of the previous lane, E[3..10] = own 16 samples, E[11..13] = next lane's first 6
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    uint32_t S[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) S[k] = __builtin_amdgcn_alignbit(E[k + 1], E[k], 16);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ws = j - H + 6;  // first sample of the window, counted from E[0]'s first sample (>= 1)
+        int acc = 0;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const uint32_t pair = (ws & 1) == 0 ? E[ws / 2 + m < 14 ? ws / 2 + m : 13] : S[(ws - 1) / 2 + m < 13 ? (ws - 1) / 2 + m : 12];
+            acc = m == 0 ? sdot2_first(pair, cpm[0]) : sdot2_acc(pair, cpm[m], acc);
+        }
+        Z[j] = acc;
+    }
+}
+
+struct Tile16 {
+    uint32_t d[8];
+};
+
+template <int W, bool FUSED_BASELINE>
+__global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolView pool, RecView rec, SgParams sg,
+                                                                            MaskParams mp, SpanParams sp) {
+    constexpr int H = W / 2;
+    constexpr int NP = H + 1;
+    static_assert(W % 2 == 1 && W >= 3 && W <= 11, "halo of 6 samples per side");
+    __shared__ SpanTable s_tab[kWavesPerBlock];
+    __shared__ int32_t etab[2 * H * W];
+    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
+    __syncthreads();
+    const int lane = lane_id();
+    const int wv = wave_in_block();
+    SpanTable* tab = &s_tab[wv];
+    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int L = sp.L;
+    const bool positive = sp.positive != 0;
+
+    uint32_t cpm[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        int n0 = sg.itab[2 * m];
+        int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
+        if (positive) { n0 = -n0; n1 = -n1; }
+        cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+    }
+    const uint32_t fill_raw = positive ? 0u : 0xffffffffu;
+    const uint32_t fillb = fill_raw ^ 0x80008000u;
+
+    for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
+        const int64_t r0 = span * sp.rs;
+        const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
+        const int64_t g_base = sp.off0 + r0 * L;
+        if (sp.dbg & 8) {  // measurement only: no per-record phase
+            tab->zhi[lane] = INT32_MIN; tab->zlo[lane] = INT32_MIN; tab->eb[lane] = 0; tab->nr[lane] = 0;
+        } else {
+            span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
+                                           32768.0 * (double)sg.den, tab);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        const int span_samples = nrec * L;             // multiple of 16
+        const int T = (sp.dbg & 4) ? 0 : (span_samples + 1023) / 1024;  // dbg 4: no tile loop
+        const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
+        const int last_pos = span_samples - 16;
+        auto tile_at = [&](int t) {
+            int pos = t * 1024 + lane * 16;
+            pos = pos < last_pos ? pos : last_pos;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(span_ptr + pos);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(span_ptr + pos + 8);
+            Tile16 x;
+            x.d[0] = v0.x; x.d[1] = v0.y; x.d[2] = v0.z; x.d[3] = v0.w;
+            x.d[4] = v1.x; x.d[5] = v1.y; x.d[6] = v1.z; x.d[7] = v1.w;
+            return x;
+        };
+        int rl = (lane * 16) / L;
+        int i0 = lane * 16 - rl * L;  // multiple of 16; a lane's 16 samples never straddle records (L % 16 == 0)
+        uint32_t p5 = fillb, p6 = fillb, p7 = fillb;
+        uint32_t carry_msb = 0;
+        uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
+        int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);
+        const int bm_wrap = (int)sp.bm_stride - (L >> 3);
+
+        auto do_tile = [&](int t, const Tile16& cur, const Tile16& nxt) {
+            const bool in_span = t * 1024 + lane * 16 < span_samples;
+            const int rli = in_span ? rl : 0;
+            const int zhi = in_span ? tab->zhi[rli] : INT32_MIN;
+            uint32_t E[14];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) E[3 + k] = cur.d[k] ^ 0x80008000u;
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80008000u;
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80008000u;
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80008000u;
+            E[0] = dpp_from_prev_lane(p5, E[8]);
+            E[1] = dpp_from_prev_lane(p6, E[9]);
+            E[2] = dpp_from_prev_lane(p7, E[10]);
+            E[11] = dpp_from_next_lane(n0, E[3]);
+            E[12] = dpp_from_next_lane(n1, E[4]);
+            E[13] = dpp_from_next_lane(n2, E[5]);
+            int Z[16];
+            sg_chunk16_numerators<W>(E, cpm, Z);
+
+            uint64_t cm[16];
+            uint64_t any_c = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { cm[j] = __ballot(Z[j] < zhi); any_c |= cm[j]; }
+            const bool first = i0 == 0, last = i0 == L - 16;
+            const uint64_t edge_lanes = __ballot(in_span && (first || last));
+            uint32_t bits = 0;
+            if (any_c != 0 || edge_lanes != 0) {
+                const uint32_t vb = (first ? (0xffffu << H) & 0xffffu : 0xffffu) & (last ? 0xffffu >> H : 0xffffu);
+                const int zlo = tab->zlo[rli];
+                // bits from the compare results (the compiler reuses the lane masks of the candidate test);
+                // the band test (Z > zlo) stays on lane masks in scalar registers and only becomes lane
+                // bits when some lane of the wave is inside the band
+                uint64_t any_b = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool c = Z[j] < zhi;
+                    bits |= (uint32_t)c << j;
+                    any_b |= cm[j] & __ballot(Z[j] > zlo);
+                }
+                bits &= vb;
+                uint32_t border = 0;
+                if (any_b != 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) border |= (uint32_t)(Z[j] < zhi && Z[j] > zlo) << j;
+                    border &= vb;
+                }
+                if (any_b != 0 && __ballot(border != 0) != 0) {
+                    if (border) {  // rare: the reference's float64 arithmetic decides
+                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
+                        const double baseline = tab->bl[rli], thr = tab->thr[rli];
+                        while (border) {
+                            const int j = __ffs((int)border) - 1;
+                            border &= border - 1;
+                            const double w = src.at(i0 + j);
+                            const double sig = positive ? (w - baseline) : (baseline - w);
+                            if (!(sig >= thr)) bits &= ~(1u << j);
+                        }
+                    }
+                }
+                if (in_span && (first || last)) {
+                    const uint32_t ebr = (uint32_t)tab->eb[rli];
+                    bits |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (16 - H)) & 0xffffu;
+                }
+                if (__ballot(bits != 0) != 0) {
+                    uint32_t prevb = dpp_from_prev_lane(carry_msb << 15, bits);
+                    if (first) prevb = 0;
+                    const uint32_t starts = bits & ~((bits << 1) | (prevb >> 15)) & 0xffffu;
+                    if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
+                }
+            }
+            if (in_span) *reinterpret_cast<uint16_t*>(bm_span + bm_pos) = (uint16_t)bits;
+            carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)bits, 63) >> 15) & 1u;
+            p5 = (uint32_t)__builtin_amdgcn_readlane((int)E[8], 63);
+            p6 = (uint32_t)__builtin_amdgcn_readlane((int)E[9], 63);
+            p7 = (uint32_t)__builtin_amdgcn_readlane((int)E[10], 63);
+            i0 += 1024;
+            bm_pos += 128;
+            while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
+        };
+        // ring of 3 tiles (2 x 2 KiB in flight per wave), unrolled by 3
+        Tile16 ra = tile_at(0), rb = tile_at(1), rc;
+        int t = 0;
+        for (; t + 3 <= T; t += 3) {
+            rc = tile_at(t + 2); do_tile(t, ra, rb);
+            ra = tile_at(t + 3); do_tile(t + 1, rb, rc);
+            rb = tile_at(t + 4); do_tile(t + 2, rc, ra);
+        }
+        if (t < T) { rc = tile_at(t + 2); do_tile(t, ra, rb); ++t; }
+        if (t < T) { do_tile(t, rb, rc); ++t; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < nrec) mp.rec_nhits[r0 + lane] = tab->nr[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // ---- K2 (span mode): materialised wave_pool_filtered from exact integer numerators ---------------------
 // Same tiling as k_sg_mask_span; every lane turns its 8 numerators into float32 with
 // y = f32(f64(n.x) * (1/den)) (equal to scipy's float32 output for |n.x| >= guard) and
@@ -1137,16 +1330,18 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
 }
 
 // ---- A (span mode, matrix cores): the FIR as a banded matrix product -----------------------------------
-// Same contract as k_sg_mask_span, for L % 32 == 0 and |n_k| <= 127.  Measured: the integer VALU issues
-// one wave64 op per ~4.2 cycles (tools/valu_rate.hip), so 48 dot2 + 9 perm per tile make the dot2 kernel
-// VALU-bound at ~0.36 of HBM peak.  Here the 11-tap sums run on v_mfma_i32_16x16x64_i8:
-//   A (16 x 64 bytes)  = the wave's 64 loaded chunks as they sit in registers: lane l = 16q + r holds
-//                        chunk l = k-quarter q of row r (bytes biased by -128 with one xor per dword),
-//   B (64 x 16)        = host-built band matrix: k-quarter 0/1 (set a) or 2/3 (set b) -> 8 output
-//                        columns each, rows of the low bytes (P) or the high bytes (Q) carry n[tap],
-//   D (16 x 16 int32)  = partial sums; numerator Z = P + 256 Q (+ constant folded into the band).
-// Three A operands (previous / own / next chunk, halo over DPP) x {a,b} x {P,Q} = 12 MFMAs per tile.
-// A compare on D register i gives a 64-bit lane mask whose 8 bytes ARE the mask bytes of 8 chunks.
+// Same contract as k_sg_mask_span, for |n_k| <= 127.  Measured: the integer VALU issues one wave64 op
+// per ~4.2 cycles (tools/valu_rate.hip), so 48 dot2 + 9 perm + 8 mov per tile make the dot2 kernel
+// VALU-bound at ~0.33 of HBM peak.  Here the 11-tap sums run on v_mfma_i32_16x16x64_i8, D = A x B with
+//   B (64 x 16 bytes) = the wave's 64 loaded chunks exactly as they sit in registers: lane l = 16g + c
+//                       holds k-quarter g of column c, i.e. chunk l (bytes biased by -128: one xor/dword),
+//   A (16 x 64)       = host-built band matrix: row 4g + i reads only k-quarter g and carries the taps
+//                       of output i on the low-byte (P) or high-byte (Q) positions,
+//   D (16 x 16 int32) : lane l = 16g + c receives rows 4g + i, i = 0..3  ==  outputs 0..3 of ITS OWN chunk.
+// The same A applied to the data shifted by 4 samples (registers [d2,d3,next.d0,next.d1]: no instruction)
+// gives outputs 4..7.  Three shifts (previous / own / next chunk, halo over DPP) x {P,Q} x {0..3, 4..7}
+// = 12 MFMAs per tile; numerator Z = P + 256 Q (+ a constant folded into the band).  Everything after
+// the numerators is identical to k_sg_mask_span.
 typedef int wfa_v4i __attribute__((ext_vector_type(4)));
 
 template <int W, bool FUSED_BASELINE>
@@ -1155,7 +1350,6 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span_mfma(PoolView pool, Rec
     constexpr int H = W / 2;
     __shared__ SpanTable s_tab[kWavesPerBlock];
     __shared__ int32_t etab[2 * H * W];
-    __shared__ uint64_t s_words[kWavesPerBlock][8];
     for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
     __syncthreads();
     const int lane = lane_id();
@@ -1166,22 +1360,14 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span_mfma(PoolView pool, Rec
     const int L = sp.L;
     const bool positive = sp.positive != 0;
 
-    // band matrices in operand layout: [polarity][shift prev/own/next][set a/b][part P/Q][lane] x 16 B
-    const wfa_v4i* __restrict__ btab = reinterpret_cast<const wfa_v4i*>(sg.mfma_tab) + (positive ? 12 * 64 : 0);
-    wfa_v4i B[12];
+    // band matrices in A-operand layout: [polarity][shift prev/own/next][part P/Q][lane] x 16 B
+    const wfa_v4i* __restrict__ atab = reinterpret_cast<const wfa_v4i*>(sg.mfma_tab) + (positive ? 6 * 64 : 0);
+    wfa_v4i A[6];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) B[k] = btab[k * 64 + lane];
+    for (int k = 0; k < 6; ++k) A[k] = atab[k * 64 + lane];
     const double bias = 32896.0 * (double)sg.den;  // 128 * (1 + 256) * sum(n)
-    const int bias_i = 32896 * sg.den;
-    const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
-    const uint32_t fillb = (positive ? 0u : 0xffffffffu) ^ 0x80808080u;
-
-    // scattered (result) layout of this lane: column c = lane & 15, row group g = lane >> 4;
-    // D register i of set a <-> chunk 4g + 16h + i, sample c & 7 (h = c >> 3); set b: + 32 chunks
-    const int qa = 4 * (lane >> 4) + 16 * ((lane >> 3) & 1);
-    // natural layout -> (word, byte) of the ballot words holding this lane's chunk
-    const int nat_word = 4 * (lane >> 5) + (lane & 3);
-    const int nat_byte = 2 * ((lane & 15) >> 2) + ((lane >> 4) & 1);
+    const uint32_t fill_raw = positive ? 0u : 0xffffffffu;
+    const uint32_t fillb = fill_raw ^ 0x80808080u;
 
     for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
         const int64_t r0 = span * sp.rs;
@@ -1202,135 +1388,114 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span_mfma(PoolView pool, Rec
             x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
             return x;
         };
-        // natural layout bookkeeping (lane = chunk): record, position, bitmap byte
         int rl = (lane * 8) / L;
         int i0 = lane * 8 - rl * L;
+        uint32_t p1 = fillb, p2 = fillb, p3 = fillb;
+        uint32_t carry_msb = 0;
         uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
         int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);
         const int bm_wrap = (int)sp.bm_stride - (L >> 3);
-        // scattered layout bookkeeping: record of the 4-chunk groups of set a / set b (L % 32 == 0)
-        int rla = (qa * 8) / L, ia = qa * 8 - rla * L;
-        int rlb = (qa * 8 + 256) / L, ib = qa * 8 + 256 - rlb * L;
-        uint32_t p1 = fillb, p2 = fillb, p3 = fillb;
-        uint32_t carry_msb = 0;
 
         auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
-            wfa_v4i a_own, a_prev, a_next;
+            const bool in_span = t * 512 + lane * 8 < span_samples;
+            const int rli = in_span ? rl : 0;
+            const int zhi = in_span ? tab->zhi[rli] : INT32_MIN;
+
+            // R[0..3] previous chunk, R[4..7] own, R[8..11] next (dwords, bytes biased)
+            uint32_t R[12];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a_own[k] = (int)(cur.d[k] ^ 0x80808080u);
+            for (int k = 0; k < 4; ++k) R[4 + k] = cur.d[k] ^ 0x80808080u;
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80808080u;
             const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80808080u;
             const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80808080u;
-            a_prev[0] = a_own[0];  // samples 0,1 of the previous chunk are outside every window (H <= 7... B rows are 0)
-            a_prev[1] = (int)dpp_from_prev_lane(p1, (uint32_t)a_own[1]);
-            a_prev[2] = (int)dpp_from_prev_lane(p2, (uint32_t)a_own[2]);
-            a_prev[3] = (int)dpp_from_prev_lane(p3, (uint32_t)a_own[3]);
-            a_next[0] = (int)dpp_from_next_lane(n0, (uint32_t)a_own[0]);
-            a_next[1] = (int)dpp_from_next_lane(n1, (uint32_t)a_own[1]);
-            a_next[2] = (int)dpp_from_next_lane(n2, (uint32_t)a_own[2]);
-            a_next[3] = a_own[3];
+            R[0] = R[4];  // samples -8,-7 never enter a window (H <= 7): rows of A are zero there
+            R[1] = dpp_from_prev_lane(p1, R[5]);
+            R[2] = dpp_from_prev_lane(p2, R[6]);
+            R[3] = dpp_from_prev_lane(p3, R[7]);
+            R[8] = dpp_from_next_lane(n0, R[4]);
+            R[9] = dpp_from_next_lane(n1, R[5]);
+            R[10] = dpp_from_next_lane(n2, R[6]);
+            R[11] = R[7];  // samples 14,15 of the next chunk: zero rows as well
             const wfa_v4i zero = {0, 0, 0, 0};
-            wfa_v4i Pa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[0], zero, 0, 0, 0);
-            wfa_v4i Qa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[1], zero, 0, 0, 0);
-            wfa_v4i Pb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[2], zero, 0, 0, 0);
-            wfa_v4i Qb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_prev, B[3], zero, 0, 0, 0);
-            Pa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[4], Pa, 0, 0, 0);
-            Qa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[5], Qa, 0, 0, 0);
-            Pb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[6], Pb, 0, 0, 0);
-            Qb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_own, B[7], Qb, 0, 0, 0);
-            Pa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[8], Pa, 0, 0, 0);
-            Qa = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[9], Qa, 0, 0, 0);
-            Pb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[10], Pb, 0, 0, 0);
-            Qb = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_next, B[11], Qb, 0, 0, 0);
-
-            const bool in_a = t * 512 + qa * 8 < span_samples, in_b = t * 512 + qa * 8 + 256 < span_samples;
-            const int rla_i = in_a ? rla : 0, rlb_i = in_b ? rlb : 0;
-            const int zhi_a = in_a ? tab->zhi[rla_i] : INT32_MIN, zhi_b = in_b ? tab->zhi[rlb_i] : INT32_MIN;
+            auto opnd = [&](int first) {
+                wfa_v4i v;
+                v[0] = (int)R[first]; v[1] = (int)R[first + 1];
+                v[2] = (int)R[first + 2 < 12 ? first + 2 : 11]; v[3] = (int)R[first + 3 < 12 ? first + 3 : 11];
+                return v;
+            };
+            // outputs 0..3: data windows R[0:3], R[4:7], R[8:11]; outputs 4..7: the same shifted by 4 samples
+            const wfa_v4i b_prev = opnd(0), b_own = opnd(4), b_next = opnd(8);
+            const wfa_v4i c_prev = opnd(2), c_own = opnd(6), c_next = opnd(10);
+            wfa_v4i P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], b_prev, zero, 0, 0, 0);
+            wfa_v4i Q1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], b_prev, zero, 0, 0, 0);
+            wfa_v4i P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], c_prev, zero, 0, 0, 0);
+            wfa_v4i Q2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], c_prev, zero, 0, 0, 0);
+            P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], b_own, P1, 0, 0, 0);
+            Q1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], b_own, Q1, 0, 0, 0);
+            P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], c_own, P2, 0, 0, 0);
+            Q2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], c_own, Q2, 0, 0, 0);
+            P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[4], b_next, P1, 0, 0, 0);
+            Q1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[5], b_next, Q1, 0, 0, 0);
+            P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[4], c_next, P2, 0, 0, 0);
+            Q2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[5], c_next, Q2, 0, 0, 0);
             int Z[8];
-            uint64_t cm[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                Z[i] = Pa[i] + (Qa[i] << 8);
-                Z[4 + i] = Pb[i] + (Qb[i] << 8);
-                cm[i] = __ballot(Z[i] < zhi_a);
-                cm[4 + i] = __ballot(Z[4 + i] < zhi_b);
+                Z[i] = P1[i] + (Q1[i] << 8);
+                Z[4 + i] = P2[i] + (Q2[i] << 8);
             }
+
+            uint64_t cm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cm[j] = __ballot(Z[j] < zhi);
             const uint64_t any_c = cm[0] | cm[1] | cm[2] | cm[3] | cm[4] | cm[5] | cm[6] | cm[7];
-            const bool in_span = t * 512 + lane * 8 < span_samples;
             const bool first = i0 == 0, last = i0 == L - 8;
-            const uint64_t edge_lanes = __ballot(in_span && (first || last) && tab->eb[in_span ? rl : 0] != 0);
+            const uint64_t edge_lanes = __ballot(in_span && (first || last));
             uint32_t byte = 0;
             if (any_c != 0 || edge_lanes != 0) {
-                // borderline elements (inside the band): the float64 predicate of the reference on
-                // y = f32(Y/den); Y >= guard always holds here or the element is left to the literal check
-                const int zlo_a = tab->zlo[rla_i], zlo_b = tab->zlo[rlb_i];
-                uint64_t bd[8];
+                const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
+                const int zlo = tab->zlo[rli];
+                uint32_t border = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    bd[i] = __ballot(Z[i] < zhi_a && Z[i] > zlo_a);
-                    bd[4 + i] = __ballot(Z[4 + i] < zhi_b && Z[4 + i] > zlo_b);
+                for (int j = 0; j < 8; ++j) {
+                    const bool c = Z[j] < zhi;
+                    byte |= (uint32_t)c << j;
+                    border |= (uint32_t)(c && Z[j] > zlo) << j;
                 }
-                if ((bd[0] | bd[1] | bd[2] | bd[3] | bd[4] | bd[5] | bd[6] | bd[7]) != 0) {
-                    const double bl_a = tab->bl[rla_i], th_a = tab->thr[rla_i];
-                    const double bl_b = tab->bl[rlb_i], th_b = tab->thr[rlb_i];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (bd[i] == 0) continue;
-                        const bool isb = i >= 4;
-                        const int zlo = isb ? zlo_b : zlo_a, zhi = isb ? zhi_b : zhi_a;
-                        bool m = Z[i] < zhi;
-                        if (m && Z[i] > zlo) {
-                            const int y_num = (positive ? -Z[i] : Z[i]) + bias_i;
-                            const double bl = isb ? bl_b : bl_a, th = isb ? th_b : th_a;
-                            if (y_num >= guard) {
-                                const double y = (double)(float)((double)y_num * sg.rden);
-                                m = (positive ? (y - bl) : (bl - y)) >= th;
-                            } else {  // below the integer guard: literal float64 chain
-                                const int rli = isb ? rlb_i : rla_i;
-                                const int pos_in_rec = (isb ? ib : ia) + 8 * (i & 3) + (lane & 7);
-                                WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
-                                const double w = src.at(pos_in_rec);
-                                m = (positive ? (w - bl) : (bl - w)) >= th;
-                            }
+                byte &= vb;
+                border &= vb;
+                if (__ballot(border != 0) != 0) {
+                    if (border) {  // rare: the reference's float64 arithmetic decides
+                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
+                        const double baseline = tab->bl[rli], thr = tab->thr[rli];
+                        while (border) {
+                            const int j = __ffs((int)border) - 1;
+                            border &= border - 1;
+                            const double w = src.at(i0 + j);
+                            const double sig = positive ? (w - baseline) : (baseline - w);
+                            if (!(sig >= thr)) byte &= ~(1u << j);
                         }
-                        cm[i] = __ballot(m);
                     }
                 }
-                // natural layout: this lane's chunk byte out of the 8 mask words
-                if (lane < 8) {
-                    uint64_t w = cm[0];
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) w = lane == k ? cm[k] : w;
-                    s_words[wv][lane] = w;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                byte = reinterpret_cast<const uint8_t*>(&s_words[wv][0])[nat_word * 8 + nat_byte];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
-                byte &= vb;
-                if (!in_span) byte = 0;
                 if (in_span && (first || last)) {
-                    const uint32_t ebr = (uint32_t)tab->eb[rl];
+                    const uint32_t ebr = (uint32_t)tab->eb[rli];
                     byte |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (8 - H)) & 0xffu;
                 }
                 if (__ballot(byte != 0) != 0) {
                     uint32_t prevb = dpp_from_prev_lane(carry_msb << 7, byte);
                     if (first) prevb = 0;
                     const uint32_t starts = byte & ~((byte << 1) | (prevb >> 7)) & 0xffu;
-                    if (starts) atomicAdd(&tab->nr[rl], __popc(starts));
+                    if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
                 }
             }
             if (in_span) bm_span[bm_pos] = (uint8_t)byte;
             carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
-            p1 = (uint32_t)__builtin_amdgcn_readlane(a_own[1], 63);
-            p2 = (uint32_t)__builtin_amdgcn_readlane(a_own[2], 63);
-            p3 = (uint32_t)__builtin_amdgcn_readlane(a_own[3], 63);
-            i0 += 512; bm_pos += 64;
+            p1 = (uint32_t)__builtin_amdgcn_readlane((int)R[5], 63);
+            p2 = (uint32_t)__builtin_amdgcn_readlane((int)R[6], 63);
+            p3 = (uint32_t)__builtin_amdgcn_readlane((int)R[7], 63);
+            i0 += 512;
+            bm_pos += 64;
             while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
-            ia += 512;
-            while (ia >= L) { ia -= L; ++rla; }
-            ib += 512;
-            while (ib >= L) { ib -= L; ++rlb; }
         };
         Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
         int t = 0;
@@ -1504,14 +1669,46 @@ __device__ __forceinline__ int dpp_i32(int v, int ctrl_sel) {
 // fast path: 8 lanes per hit.  Lane q of a group loads the aligned 16-byte chunk (c - 1 + q); lanes
 // 1..6 produce the 8 outputs of their chunk from exact integer numerators (halo over DPP), lanes 0 and
 // 7 only provide halo.  48 window samples per round, one coalesced 128-byte read per group.
+// Hit windows are strongly bimodal (fragments of a few samples vs. pulses of 100-300), and a wave iterates
+// as long as its longest hit.  Each 1024-thread block therefore ranks its 128 hits by window length in
+// LDS first, so that the 8 hits sharing a wave need about the same number of rounds.
+constexpr int kRowsBlock = 1024;
+constexpr int kRowsHits = kRowsBlock / 8;
+
 template <int W>
-__global__ __launch_bounds__(kBlock) void k_hit_rows_grp(PoolView pool, RecView rec, SgParams sg, RowParams rp,
-                                                         int4* __restrict__ desc, int64_t n_hits,
-                                                         uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecView rec, SgParams sg, RowParams rp,
+                                                             int4* __restrict__ desc, int64_t n_hits,
+                                                             uint8_t* __restrict__ out) {
     constexpr int H = W / 2;
     constexpr int NP = H + 1;
+    __shared__ int s_len[kRowsHits];
+    __shared__ int s_perm[kRowsHits];
     const int q = threadIdx.x & 7;
-    const int64_t h = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 3;
+    const int grp = threadIdx.x >> 3;
+    const int64_t h_base = (int64_t)blockIdx.x * kRowsHits;
+    {
+        // window length of the hit in this group's slot (0 = nothing to do), then rank = position in
+        // descending order (ties by slot), computed by the group's 8 lanes over 16 slots each
+        const int64_t h0 = h_base + grp;
+        int len = 0;
+        if (h0 < n_hits) {
+            const int4 d0 = desc[h0];
+            if (d0.w == 0) len = d0.z - d0.y + rp.le + rp.re;
+        }
+        if (q == 0) s_len[grp] = len;
+        __syncthreads();
+        int cnt = 0;
+        for (int j = q; j < kRowsHits; j += 8) {
+            const int lj = s_len[j];
+            cnt += (lj > len || (lj == len && j < grp)) ? 1 : 0;
+        }
+        cnt += dpp_i32(cnt, 0);
+        cnt += dpp_i32(cnt, 1);
+        cnt += dpp_i32(cnt, 2);
+        if (q == 0) s_perm[cnt] = grp;
+        __syncthreads();
+    }
+    const int64_t h = h_base + s_perm[grp];
     const bool live = h < n_hits;
     int4 d = make_int4(0, 0, 0, 1);
     if (live) d = desc[h];
@@ -2149,7 +2346,8 @@ hipError_t launch_savgol_span(hipStream_t st, const PoolView& pool, const RecVie
 }
 
 bool sg_mask_mfma_supported(const SgParams& sg, int L) {
-    return sg.mfma_tab != nullptr && (L % 32) == 0 && sg.W >= 5 && sg.W <= 15;
+    (void)L;
+    return sg.mfma_tab != nullptr && sg.W >= 5 && sg.W <= 15;
 }
 
 hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
@@ -2176,6 +2374,35 @@ hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const P
         default: return hipErrorInvalidValue;
     }
 #undef WFA_SPANM
+    return hipGetLastError();
+}
+
+bool sg_mask_span16_supported(const SgParams& sg, int L) {
+    return sg.int_ok && (L % 16) == 0 && L >= 32 && sg.W >= 5 && sg.W <= 11;
+}
+
+hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
+                                 const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
+    int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t resident = 256 * WFA_SPAN_WAVES;
+    if (g < 1) g = 1;
+    if (g > resident) g = resident;
+    const int grid = (int)g;
+#define WFA_SPAN16(WW)                                                                                              \
+    case WW:                                                                                                        \
+        if (fused_baseline)                                                                                         \
+            hipLaunchKernelGGL((k_sg_mask_span16<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp);  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_sg_mask_span16<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp); \
+        break;
+    switch (sg.W) {
+        WFA_SPAN16(5)
+        WFA_SPAN16(7)
+        WFA_SPAN16(9)
+        WFA_SPAN16(11)
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_SPAN16
     return hipGetLastError();
 }
 
@@ -2219,9 +2446,9 @@ hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bi
 hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
                                 const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out) {
     if (n_hits == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((n_hits * 8 + kBlock - 1) / kBlock);
+    const unsigned grid = (unsigned)((n_hits + kRowsHits - 1) / kRowsHits);
 #define WFA_ROWS(WW) \
-    case WW: hipLaunchKernelGGL((k_hit_rows_grp<WW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); break;
+    case WW: hipLaunchKernelGGL((k_hit_rows_grp<WW>), dim3(grid), dim3(kRowsBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); break;
     switch (sg.W) {
         WFA_ROWS(5)
         WFA_ROWS(7)

@@ -116,6 +116,9 @@ hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolVi
                                const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 hipError_t launch_savgol_span(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
                               const SpanParams& sp, float* out);
+bool sg_mask_span16_supported(const SgParams& sg, int L);
+hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
+                                 const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 bool sg_mask_mfma_supported(const SgParams& sg, int L);
 hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                     const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
