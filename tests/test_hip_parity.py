@@ -263,3 +263,51 @@ def test_rccl_single_rank_gather(sess):
     G.assert_struct_equal(rows, hits, what="gather of resident rows")
     counts, rows = sess.rccl_gather_rows(hits[:7], 7, hits.dtype, root=0)
     G.assert_struct_equal(rows, hits[:7], what="gather of host rows")
+
+
+def test_full_size_properties():
+    """BASELINE config sizes (10^8 samples, 16-ch V1725): properties that do not need the oracle at scale.
+
+    * determinism: two runs give identical rows;
+    * order: rows sorted by (record, window start), windows inside the record, position inside the window;
+    * two independent code paths agree: fused integer pass (mask/scan/runs/rows) vs materialised
+      float32 pool (k_savgol_span) + literal float64 hit kernel on it: integer fields bit-exact;
+    * checksum of checksums: per-record run counts sum to the number of rows;
+    * oracle spot check on 2000 records drawn across the whole run.
+    """
+    n_rec = 125_000  # x 800 = 1e8 samples
+    rec, pool = synth.make_run(n_rec, "v1725", cfg=1)
+    with DeviceSession(0) as s:
+        s.upload_pool(pool)
+        blank = rec.copy()
+        blank["baseline"] = np.nan
+        s.upload_records(blank, 10.0)
+        s.set_sg_plan(11, 2)
+        fused = s.fused_baseline_filter_hits((0, 40))
+        again = s.fused_baseline_filter_hits((0, 40))
+        np.testing.assert_array_equal(fused.view(np.uint8), again.view(np.uint8))
+        np.testing.assert_array_equal(s.baseline_mean(0, 40), rec["baseline"])
+
+        rid = fused["record_id"]
+        assert np.all(np.diff(rid) >= 0)
+        same = np.diff(rid) == 0
+        assert np.all(np.diff(fused["edge_start"].astype(np.int64))[same] > 0)
+        assert np.all((fused["edge_start"] >= 0) & (fused["edge_end"] <= 800) & (fused["edge_start"] < fused["edge_end"]))
+        assert np.all((fused["position"] >= fused["edge_start"]) & (fused["position"] < fused["edge_end"]))
+        assert np.all(fused["width"] == (fused["edge_end"] - fused["edge_start"]).astype(np.float32))
+        assert np.all(fused["integral"] >= 0) and np.all(np.isfinite(fused["height"]))
+        counts = np.bincount(rid, minlength=n_rec)
+        assert counts.sum() == len(fused) and len(fused) > n_rec  # ~1.7 hits per record
+
+        s.upload_records(rec, 10.0)
+        s.savgol(download=False)
+        via_pool = s.threshold_hits(_lib.SRC_F32)
+        G.assert_struct_equal(via_pool, fused, float_rtol=FLOAT_RTOL, what="fused vs materialised path")
+
+    pick = np.sort(np.random.default_rng(0).choice(n_rec, 2000, replace=False))
+    sub = rec[pick].copy()
+    sub_pool = pool.reshape(-1, 800)[pick].reshape(-1)
+    sub["wave_offset"] = np.arange(len(pick), dtype=np.int64) * 800
+    want = O.threshold_hits_chunked(sub, O.filter_wave_pool_uniform(sub_pool, 800))
+    got = fused[np.isin(fused["record_id"], rec["record_id"][pick])]
+    G.assert_struct_equal(got, want, float_rtol=FLOAT_RTOL, what="oracle spot check")
