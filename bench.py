@@ -82,6 +82,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threshold", type=float, default=10.0, help="hit threshold (reference default 10.0)")
     ap.add_argument("--no-features", action="store_true", help="skip the untimed feature / filter kernels")
+    ap.add_argument("--grouping", action="store_true",
+                    help="also run the event grouping of the (gathered) hit rows on rank 0 (untimed extra)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,6 +149,7 @@ def main() -> None:
     # ---- event-grouping exchange (RCCL over xGMI), outside the timed region ---------------------------
     gather_ms = None
     gather_note = None
+    rows = None
     total_hits = n_hits
     if dist is not None:
         from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
@@ -178,6 +181,16 @@ def main() -> None:
         extra_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in sess.profile_report().items()}
         sess.profile(False)
 
+    grouping = None
+    if rank == 0 and args.grouping:
+        from waveformanalysis_amd.event_grouping import group_hit_windows_flat
+
+        all_rows = rows if (dist is not None and gather_ms is not None) else sess._fill_hits(n_hits)
+        t0 = time.perf_counter()
+        flat = group_hit_windows_flat(all_rows, 100.0)
+        grouping = {"hits": int(len(all_rows)), "events": int(len(flat["event_start"]) - 1),
+                    "host_ms": round((time.perf_counter() - t0) * 1e3, 1), "time_window_ns": 100.0}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_samples * n_gpus / (elapsed / args.steps) / 1e9
@@ -207,7 +220,7 @@ def main() -> None:
             "dtype": "u16 samples; int32 exact-rational SG + f64 hit windows",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.preset} 16-ch synthetic chunk, {len(records)} records x {L} samples "
+                "workload": f"{args.preset} {synth.PRESETS[args.preset][2] * synth.PRESETS[args.preset][3]}-ch synthetic chunk, {len(records)} records x {L} samples "
                             f"= {n_samples:.4g} samples per GPU; fused baseline(first 40) + SG(11,2) + "
                             "threshold hits (thr 10, ext 2/2), hit rows left on device",
                 "samples_per_gpu": n_samples,
@@ -236,6 +249,8 @@ def main() -> None:
             out["config"]["hits_total"] = total_hits
         if gather_note:
             out["gather_note"] = gather_note
+        if grouping:
+            out["event_grouping"] = grouping
         if not args.no_cpu_baseline:
             n_cpu = min(args.cpu_records, len(records))
             cb = cpu_baseline(records, pool, n_cpu)

@@ -352,3 +352,47 @@ def width_integral(records: np.ndarray, wave_pool: np.ndarray, *, q_low=0.10, q_
     if rows:
         return np.array(rows, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)
     return np.zeros(0, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)
+
+
+# --- a15: event grouping ----------------------------------------------------------------------
+def group_hit_windows_literal(hits: np.ndarray, time_window_ns: float):
+    """event_grouping.py:286-471, literal gap-chain loop; returns a list of events
+    (t_min, t_max, member hit indices in the reference's per-event order)."""
+    names = set(hits.dtype.names or ())
+    s_name, e_name = ("sample_start", "sample_end") if {"sample_start", "sample_end"} <= names else ("edge_start", "edge_end")
+    ts = np.asarray(hits["timestamp"], dtype=np.int64)
+    pos = np.asarray(hits["position"], dtype=np.float64)
+    dt = np.asarray(hits["dt"], dtype=np.int32)
+    s_rel = np.asarray(hits[s_name], dtype=np.int32)
+    e_rel = np.asarray(hits[e_name], dtype=np.int32)
+    rid = np.asarray(hits["record_id"], dtype=np.int64)
+    boards = np.asarray(hits["board"], dtype=np.int16)
+    channels = np.asarray(hits["channel"], dtype=np.int16)
+    dt_ps = dt.astype(np.float64) * 1e3
+    a_s = ts.astype(np.float64) + (s_rel - pos) * dt_ps
+    a_e = ts.astype(np.float64) + (e_rel - pos) * dt_ps
+    if len(hits) == 0:
+        return []
+    order = np.lexsort((rid, ts, dt, a_s))
+    gap_ps = time_window_ns * 1e3
+
+    def build(idxs):
+        sub = np.asarray(idxs, dtype=np.int64)
+        k = np.lexsort((rid[sub], ts[sub], a_s[sub], dt[sub], channels[sub], boards[sub]))
+        sub = sub[k]
+        return int(np.min(a_s[sub])), int(np.max(a_e[sub])), sub
+
+    events = []
+    cur = [int(order[0])]
+    cluster_end = float(a_e[order[0]])
+    for idx in order[1:]:
+        idx = int(idx)
+        if a_s[idx] <= cluster_end + gap_ps:
+            cur.append(idx)
+            cluster_end = max(cluster_end, float(a_e[idx]))
+        else:
+            events.append(build(cur))
+            cur = [idx]
+            cluster_end = float(a_e[idx])
+    events.append(build(cur))
+    return events

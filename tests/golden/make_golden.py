@@ -159,6 +159,26 @@ def ragged_case(seed=7):
     return records, pool
 
 
+def grouping_case(name, hits, windows):
+    """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
+    from waveform_analysis.core.processing.event_grouping import group_hit_windows
+
+    out = {"hits": hits, "windows": np.asarray(windows, dtype=np.float64)}
+    for tw in windows:
+        df = group_hit_windows(hits, time_window_ns=float(tw))
+        tag = f"w{int(tw)}"
+        out[f"{tag}_t_min"] = df["t_min"].to_numpy(dtype=np.int64)
+        out[f"{tag}_t_max"] = df["t_max"].to_numpy(dtype=np.int64)
+        out[f"{tag}_n_hits"] = df["n_hits"].to_numpy(dtype=np.int64)
+        out[f"{tag}_dt_ns"] = df["dt/ns"].to_numpy(dtype=np.float64)
+        for col in ("dt", "boards", "channels", "heights", "integrals", "timestamps", "record_ids",
+                    "sample_starts", "sample_ends"):
+            out[f"{tag}_{col}"] = np.concatenate(list(df[col])) if len(df) else np.zeros(0)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(hits)} hits, windows {list(windows)} -> {os.path.getsize(path)} B")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
 
@@ -223,6 +243,13 @@ def main():
                                                             "0:7": {"threshold": 300.0}}},
              bf_cfg={"channel_config": {"0:3": {"fixed_baseline": 8000.0},
                                         "defaults": {"fixed_baseline": None}}})
+
+    # event grouping of threshold hits from a 16-channel run and from a 256-channel run
+    for preset, cfg, nrec in (("v1725", 8, 400), ("vx2730", 9, 600)):
+        rec, pool = synth.make_run(nrec, preset, cfg=cfg)
+        ctx = Ctx({"wave_source": "records", "threshold": 15.0}, {"records": rec, "wave_pool": pool})
+        hits = ThresholdHitPlugin().compute(ctx, "run")
+        grouping_case(f"grouping_{preset}", hits, (0, 100, 5000, 2000000))
 
     # large timestamps (float64 rounding of the hit timestamp), saturated + near-zero samples
     rec, pool = synth.make_run(16, "v1725", cfg=4)

@@ -13,8 +13,18 @@ from waveformanalysis_amd.channel_config import per_record_option, scatter_per_r
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+def case_names(prefix_exclude=("grouping_",)):
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return [n for n in names if not n.startswith(tuple(prefix_exclude))]
+
+
+def grouping_case_names():
+    return [n for n in case_names(prefix_exclude=()) if n.startswith("grouping_")]
+
+
+def load_grouping(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
 
 
 def load_case(name):

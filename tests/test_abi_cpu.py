@@ -89,8 +89,9 @@ def test_channel_config_layers():
 
 def test_plugin_contract_attributes():
     for p in hip_default():
-        assert p.provides and p.save_when == "always" and p.output_dtype is not None
-        assert "wave_source" in p.options or p.provides == "wave_pool_filtered"
+        assert p.provides and p.save_when == "always"
+        assert p.output_dtype is not None or p.provides == "hit_grouped"  # DataFrame product
+        assert "wave_source" in p.options or p.provides in ("wave_pool_filtered", "hit_grouped")
     hit = [p for p in hip_default() if p.provides == "hit_threshold"][0]
     ctx = SimpleContext({"use_filtered": True})
     assert hit.resolve_depends_on(ctx) == ["records", "wave_pool_filtered"]
