@@ -109,6 +109,14 @@ int wfa_baseline_mean(wfa_ctx* ctx, int32_t start, int32_t end, int update_recor
  * WFA_SRC_F32 pool; out may be NULL. */
 int wfa_savgol(wfa_ctx* ctx, float* out);
 
+/* K3 wave_pool_filtered, Butterworth branch: scipy.signal.sosfiltfilt per record, float64 recursion,
+ * float32 result (reference: filtering.py:84-101,198-224).  sos = n_sections x 6 coefficients from
+ * scipy.signal.butter(..., output="sos"), zi = n_sections x 2 from scipy.signal.sosfilt_zi, padlen =
+ * the reference's _estimate_sosfiltfilt_padlen; records with length <= padlen are copied.  The result
+ * stays resident as the WFA_SRC_F32 pool; out may be NULL.  n_sections <= 8. */
+int wfa_sosfiltfilt(wfa_ctx* ctx, int n_sections, const double* sos, const double* zi, int32_t padlen,
+                    float* out);
+
 /* K4 threshold hits (reference: hit_finder.py:231-255,329-413).  Two-phase so the caller can
  * allocate the structured array: _count runs the pass and returns the number of rows,
  * _fill copies them (THRESHOLD_HIT_DTYPE, 60-byte packed rows, order = record index, start).

@@ -311,3 +311,36 @@ def test_full_size_properties():
     want = O.threshold_hits_chunked(sub, O.filter_wave_pool_uniform(sub_pool, 800))
     got = fused[np.isin(fused["record_id"], rec["record_id"][pick])]
     G.assert_struct_equal(got, want, float_rtol=FLOAT_RTOL, what="oracle spot check")
+
+
+def test_butterworth_sosfiltfilt_bit_exact(sess):
+    """Butterworth branch of wave_pool_filtered: the lane-per-record kernel runs scipy's sosfiltfilt
+    recursion literally -> bit-exact float32 against the reference fixture and the oracle."""
+    from waveformanalysis_amd.plugins.wave_pool_filtered import design_bw
+
+    case = G.load_case("v1725_bw")
+    fp = G.filter_params(case)
+    sos, zi, padlen = design_bw(fp["lowcut"], fp["highcut"], fp["fs"], fp["filter_order"])
+    sess.upload_pool(case["wave_pool"])
+    sess.upload_records(case["records"])
+    got = sess.sosfiltfilt(sos, zi, padlen)
+    np.testing.assert_array_equal(got, case["wave_pool_filtered"])
+    # hits on the resident Butterworth-filtered pool == reference hits on its filtered pool
+    hp = G.hit_params(case)
+    sess.upload_records(case["records"], hp["thresholds"])
+    G.assert_struct_equal(sess.threshold_hits(_lib.SRC_F32, hp["left_extension"], hp["right_extension"]),
+                          case["hits_filt"], float_rtol=FLOAT_RTOL, what="hits on BW pool")
+
+    # ragged records (several shorter than padlen -> copied), different band
+    rag = G.load_case("ragged_mixed")
+    sos2, zi2, padlen2 = design_bw(0.02, 0.15, 0.5, 2)
+    want = O.filter_wave_pool(rag["records"], rag["wave_pool"], "BW", bw_sos=sos2)
+    sess.upload_pool(rag["wave_pool"])
+    sess.upload_records(rag["records"])
+    np.testing.assert_array_equal(sess.sosfiltfilt(sos2, zi2, padlen2), want)
+
+    # plugin path
+    ctx = SimpleContext({"filter_type": "BW", "lowcut": fp["lowcut"], "highcut": fp["highcut"], "fs": fp["fs"]},
+                        {"records": case["records"], "wave_pool": case["wave_pool"]},
+                        plugins=[HipWavePoolFilteredPlugin()])
+    np.testing.assert_array_equal(ctx.get_data("run", "wave_pool_filtered"), case["wave_pool_filtered"])

@@ -41,6 +41,7 @@ SIGNATURES = {
     "wfa_set_sg_plan": (_int, [_p, _int, _int, _p, _p, _int, _p, _i32, _i32, _i64, _i64]),
     "wfa_baseline_mean": (_int, [_p, _i32, _i32, _int, _p]),
     "wfa_savgol": (_int, [_p, _p]),
+    "wfa_sosfiltfilt": (_int, [_p, _int, _p, _p, _i32, _p]),
     "wfa_threshold_hits_count": (_int, [_p, _int, _i32, _i32, _i32, C.POINTER(_i64)]),
     "wfa_threshold_hits_fill": (_int, [_p, _p, _i64]),
     "wfa_fused_baseline_filter_hits": (_int, [_p, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),

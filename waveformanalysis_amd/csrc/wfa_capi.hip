@@ -343,7 +343,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
-                      &c->hit_desc, &c->sg.mfma, &c->sg.tab,
+                      &c->hit_desc, &c->bw_scratch, &c->sg.mfma, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
@@ -571,6 +571,40 @@ int wfa_savgol(wfa_ctx* c, float* out) {
     if (out)
         WFA_HIP_CHECK(hipMemcpyAsync(out, c->pool_f32.ptr, (size_t)c->pool_n * sizeof(float),
                                      hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_sosfiltfilt(wfa_ctx* c, int n_sections, const double* sos, const double* zi, int32_t padlen, float* out) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, WFA_SRC_RAW))) return rc;
+    if (n_sections < 1 || n_sections > 8) return fail(WFA_E_INVALID, "n_sections must be in [1, 8], got %d", n_sections);
+    if (!sos || !zi || padlen < 0) return fail(WFA_E_INVALID, "bad sosfiltfilt arguments");
+    if ((rc = c->pool_f32.ensure((size_t)c->pool_n * sizeof(float)))) return rc;
+    WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
+    if (c->R > 0) {
+        // forward-pass scratch: [max_len + 2 padlen][batch] float64, batches bounded to ~2 GiB
+        const int64_t n_ext = (int64_t)c->max_len + 2 * (int64_t)padlen;
+        int64_t batch = (int64_t)(2147483648LL / (n_ext * 8));
+        batch = batch / 256 * 256;
+        if (batch < 256) batch = 256;
+        if (batch > c->R) batch = (c->R + 255) / 256 * 256;
+        if ((rc = c->bw_scratch.ensure((size_t)(n_ext * batch * 8)))) return rc;
+        const PoolView pv = pool_view(c);
+        const RecView rv = rec_view(c);
+        LaunchTimer t(c);
+        for (int64_t r0 = 0; r0 < c->R; r0 += batch) {
+            const int64_t r1 = r0 + batch < c->R ? r0 + batch : c->R;
+            WFA_HIP_CHECK(launch_sosfiltfilt(c->stream, pv, rv, n_sections, sos, zi, padlen, r0, r1,
+                                             c->bw_scratch.as<double>(), batch, c->pool_f32.as<float>()));
+        }
+        if ((rc = t.end("k_sosfiltfilt"))) return rc;
+    }
+    c->have_f32 = true;
+    if (out)
+        WFA_HIP_CHECK(hipMemcpyAsync(out, c->pool_f32.ptr, (size_t)c->pool_n * sizeof(float), hipMemcpyDeviceToHost,
+                                     c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return WFA_OK;
 }

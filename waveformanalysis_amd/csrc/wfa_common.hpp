@@ -102,6 +102,7 @@ struct wfa_ctx {
     int64_t n_hits = -1;
 
     wfa::DevBuf out_rows;  // per-record feature rows
+    wfa::DevBuf bw_scratch;  // float64 forward pass of sosfiltfilt, [sample][record-in-batch]
 
     // profiling
     bool prof_on = false;

@@ -2202,6 +2202,92 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
 }
 
 // =============================================================================================
+// K3: Butterworth band-pass, scipy.signal.sosfiltfilt  (filtering.py:84-101,198-224)
+// =============================================================================================
+// sosfiltfilt is a recursive filter: strictly sequential along a record, independent across records,
+// so one lane owns one record and executes scipy's loop literally (float64, no fused multiply-add):
+//   ext  = odd extension of the float32 wave by `edge` samples at both ends (float32 arithmetic),
+//   fwd  = sosfilt(sos, ext, zi = zi0 * ext[0])       direct form II transposed, section by section:
+//              x_new = b0*x + z0 ; z0 = b1*x - a1*x_new + z1 ; z1 = b2*x - a2*x_new ; x = x_new
+//   bwd  = sosfilt(sos, reverse(fwd), zi = zi0 * fwd[-1]) ; result = reverse(bwd)[edge:-edge] -> float32
+// The forward output lives in a float64 scratch laid out [sample][record-in-batch] so the 64 lanes of a
+// wave read and write consecutive addresses.  Records with L <= padlen are copied (filtering.py:221-222).
+constexpr int kMaxSections = 8;
+
+struct SosParams {
+    int n_sections;
+    int edge;                       // padlen
+    double sos[kMaxSections][6];
+    double zi[kMaxSections][2];
+};
+
+__global__ __launch_bounds__(kBlock) void k_sosfiltfilt(PoolView pool, RecView rec, SosParams sp, int64_t r_begin,
+                                                        int64_t r_end, double* __restrict__ scratch,
+                                                        int64_t batch_stride, float* __restrict__ out) {
+    const int64_t r = r_begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= r_end) return;
+    const int L = rec.len[r];
+    if (L <= 0) return;
+    const int64_t off = rec.off[r];
+    const uint16_t* __restrict__ x = pool.u16 + off;
+    float* __restrict__ y = out + off;
+    const int edge = sp.edge;
+    if (L <= edge) {
+        for (int i = 0; i < L; ++i) y[i] = (float)x[i];
+        return;
+    }
+    double* __restrict__ col = scratch + (r - r_begin);  // element n at col[n * batch_stride]
+    const int n_ext = L + 2 * edge;
+    // float32 odd extension (scipy _arraytools.odd_ext on the float32 wave)
+    auto ext_at = [&](int n) -> double {
+        if (n < edge) return (double)(2.0f * (float)x[0] - (float)x[edge - n]);
+        if (n < edge + L) return (double)(float)x[n - edge];
+        return (double)(2.0f * (float)x[L - 1] - (float)x[L - 2 - (n - edge - L)]);
+    };
+    double z0[kMaxSections], z1[kMaxSections];
+    const double x0 = ext_at(0);
+#pragma unroll
+    for (int s = 0; s < kMaxSections; ++s) {
+        z0[s] = s < sp.n_sections ? sp.zi[s][0] * x0 : 0.0;
+        z1[s] = s < sp.n_sections ? sp.zi[s][1] * x0 : 0.0;
+    }
+    double last = 0.0;
+    for (int n = 0; n < n_ext; ++n) {
+        double xc = ext_at(n);
+#pragma unroll
+        for (int s = 0; s < kMaxSections; ++s) {
+            if (s < sp.n_sections) {
+                const double xn = sp.sos[s][0] * xc + z0[s];
+                z0[s] = sp.sos[s][1] * xc - sp.sos[s][4] * xn + z1[s];
+                z1[s] = sp.sos[s][2] * xc - sp.sos[s][5] * xn;
+                xc = xn;
+            }
+        }
+        col[(int64_t)n * batch_stride] = xc;
+        last = xc;
+    }
+#pragma unroll
+    for (int s = 0; s < kMaxSections; ++s) {
+        z0[s] = s < sp.n_sections ? sp.zi[s][0] * last : 0.0;
+        z1[s] = s < sp.n_sections ? sp.zi[s][1] * last : 0.0;
+    }
+    for (int n = n_ext - 1; n >= 0; --n) {
+        double xc = col[(int64_t)n * batch_stride];
+#pragma unroll
+        for (int s = 0; s < kMaxSections; ++s) {
+            if (s < sp.n_sections) {
+                const double xn = sp.sos[s][0] * xc + z0[s];
+                z0[s] = sp.sos[s][1] * xc - sp.sos[s][4] * xn + z1[s];
+                z1[s] = sp.sos[s][2] * xc - sp.sos[s][5] * xn;
+                xc = xn;
+            }
+        }
+        const int i = n - edge;
+        if (i >= 0 && i < L) y[i] = (float)xc;
+    }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 static inline int grid_for_records(int64_t R) {
@@ -2292,6 +2378,25 @@ hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& poo
         hipLaunchKernelGGL((k_width_integral<WFA_SRC_F32>), dim3(grid), dim3(kFeatBlock), 0, st, pool, rec, wp, out);
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecView& rec, int n_sections,
+                              const double* sos, const double* zi, int edge, int64_t r_begin, int64_t r_end,
+                              double* scratch, int64_t batch_stride, float* out) {
+    SosParams sp{};
+    sp.n_sections = n_sections;
+    sp.edge = edge;
+    for (int s = 0; s < n_sections; ++s) {
+        for (int k = 0; k < 6; ++k) sp.sos[s][k] = sos[s * 6 + k];
+        sp.zi[s][0] = zi[s * 2];
+        sp.zi[s][1] = zi[s * 2 + 1];
+    }
+    const int64_t n = r_end - r_begin;
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_sosfiltfilt, dim3(grid), dim3(kBlock), 0, st, pool, rec, sp, r_begin, r_end, scratch,
+                       batch_stride, out);
     return hipGetLastError();
 }
 

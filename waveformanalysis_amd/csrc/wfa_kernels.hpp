@@ -109,6 +109,9 @@ hipError_t launch_scan(hipStream_t st, const int32_t* counts, int64_t n, int64_t
                        int64_t* out);
 hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t* tmp_start,
                               const int32_t* nhits, const int64_t* out_start, int64_t R, uint8_t* out);
+hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecView& rec, int n_sections,
+                              const double* sos, const double* zi, int edge, int64_t r_begin, int64_t r_end,
+                              double* scratch, int64_t batch_stride, float* out);
 bool sg_mask_supported(const SgParams& sg);
 hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);

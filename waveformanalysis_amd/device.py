@@ -155,6 +155,17 @@ class DeviceSession:
         _lib.check(self._lib.wfa_savgol(self._h, _ptr(out)))
         return out
 
+    def sosfiltfilt(self, sos: np.ndarray, zi: np.ndarray, padlen: int, download: bool = True) -> np.ndarray | None:
+        """Butterworth branch of wave_pool_filtered: sos (n x 6) from scipy.signal.butter(output="sos"),
+        zi (n x 2) from scipy.signal.sosfilt_zi, padlen per filtering.py:198-203."""
+        sos = np.ascontiguousarray(sos, dtype=np.float64)
+        zi = np.ascontiguousarray(zi, dtype=np.float64)
+        if sos.ndim != 2 or sos.shape[1] != 6 or zi.shape != (sos.shape[0], 2):
+            raise ValueError("sos must be (n_sections, 6) and zi (n_sections, 2)")
+        out = np.empty(self.n_samples, dtype=np.float32) if download else None
+        _lib.check(self._lib.wfa_sosfiltfilt(self._h, int(sos.shape[0]), _ptr(sos), _ptr(zi), int(padlen), _ptr(out)))
+        return out
+
     def _fill_hits(self, n: int) -> np.ndarray:
         out = np.empty(n, dtype=THRESHOLD_HIT_DTYPE)
         _lib.check(self._lib.wfa_threshold_hits_fill(self._h, _ptr(out), n))
