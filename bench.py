@@ -38,7 +38,7 @@ from waveformanalysis_amd import synth  # noqa: E402
 from waveformanalysis_amd.device import DeviceSession  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FUSED_KERNEL = "k_sg_mask_span<baseline>"  # dominant kernel of the fused pass (uniform-length records)
+FUSED_KERNEL = "k_sg_mask_span16<baseline>"  # dominant kernel of the fused pass (uniform-length records, L % 16 == 0)
 
 
 def cpu_baseline(records: np.ndarray, pool: np.ndarray, n_records: int) -> dict:
