@@ -67,7 +67,9 @@ int wfa_sync(wfa_ctx* ctx);
  * plugins/builtin/cpu/records.py:321-331). */
 int wfa_upload_pool_u16(wfa_ctx* ctx, const uint16_t* pool, int64_t n_samples);
 
-/* wave_pool_filtered produced elsewhere (reference: records.py:334-438 output). */
+/* wave_pool_filtered produced elsewhere (reference: records.py:334-438 output).  With the same sample count as
+ * the resident wave_pool it becomes its float32 twin; with a different count it replaces the pool set (the
+ * uint16 pool is dropped and records must be uploaded again). */
 int wfa_upload_pool_f32(wfa_ctx* ctx, const float* pool, int64_t n_samples);
 
 /* Records index table as structure-of-arrays (reference row layout: processing/dtypes.py:80-100;
@@ -131,6 +133,19 @@ int wfa_threshold_hits_fill(wfa_ctx* ctx, void* out_rows, int64_t n_hits);
 int wfa_fused_baseline_filter_hits(wfa_ctx* ctx, int32_t bl_start, int32_t bl_end,
                                    int32_t left_extension, int32_t right_extension,
                                    int32_t max_len, int64_t* n_hits);
+
+/* K8 find_peaks-based hit detector, records source (reference: cpu/peak_finding.py:395-614 calling
+ * scipy.signal.find_peaks(det, height, distance, prominence, width, threshold) with scalar lower bounds, then
+ * _calculate_peak_height 567-614).  source: WFA_SRC_RAW or WFA_SRC_F32.  Two-phase like the threshold hits; rows
+ * are HIT_DTYPE (48 B packed: position i8, height f4, integral f4, edge_start f4, edge_end f4, dt i4,
+ * timestamp i8, board i2, channel i2, record_id i8) in (record, position) order.  has_threshold = 0 means
+ * threshold=None.  An empty minmax window fails with numpy's "zero-size array ..." message (WFA_E_INVALID). */
+#define WFA_HEIGHT_MINMAX 0
+#define WFA_HEIGHT_DIFF 1
+int wfa_find_peaks_count(wfa_ctx* ctx, int source, int use_derivative, double height, int has_threshold,
+                         double threshold, int32_t distance, double prominence, double width, int height_method,
+                         int32_t height_window_extension, int64_t* n_peaks);
+int wfa_find_peaks_fill(wfa_ctx* ctx, void* out_rows, int64_t n_peaks);
 
 /* K5 basic features (reference: basic_features.py:108-195).  Ranges are python slice bounds;
  * *_has_end = 0 means "None".  fixed_baseline: per-record override, NaN = none, may be NULL.

@@ -26,6 +26,8 @@ against the literal forms in tests/test_oracle_golden.py.
 
 from __future__ import annotations
 
+import math
+
 import numpy as np
 from scipy.signal import butter, savgol_filter, sosfiltfilt
 
@@ -396,3 +398,95 @@ def group_hit_windows_literal(hits: np.ndarray, time_window_ns: float):
             cluster_end = float(a_e[idx])
     events.append(build(cur))
     return events
+
+
+# --- a11: find_peaks-based hit detector -------------------------------------------------------
+HIT_DTYPE = np.dtype(
+    [
+        ("position", "i8"), ("height", "f4"), ("integral", "f4"), ("edge_start", "f4"), ("edge_end", "f4"),
+        ("dt", "i4"), ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"), ("record_id", "i8"),
+    ]
+)
+
+
+def _select_by_peak_distance(peaks: np.ndarray, priority: np.ndarray, distance: float) -> np.ndarray:
+    """scipy/signal/_peak_finding_utils.pyx `_select_by_peak_distance` (scipy 1.15), restated.
+
+    scipy orders the peaks with np.argsort(priority) (numpy's default introsort, whose order of EQUAL
+    priorities is an implementation detail: insertion sort -- stable -- up to 16 elements, vectorised
+    sorts above that on some CPUs).  The restatement pins the stable order, so among equal priorities
+    the LATER peak is visited first; without ties the result is scipy's on every platform.
+    """
+    n = peaks.shape[0]
+    distance_ = math.ceil(distance)
+    keep = np.ones(n, dtype=bool)
+    order = np.argsort(priority, kind="stable")
+    for i in range(n - 1, -1, -1):
+        j = order[i]
+        if not keep[j]:
+            continue
+        k = j - 1
+        while 0 <= k and peaks[j] - peaks[k] < distance_:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < n and peaks[k] - peaks[j] < distance_:
+            keep[k] = False
+            k += 1
+    return keep
+
+
+def find_peaks_staged(x: np.ndarray, height: float, threshold, distance: int, prominence: float, width: float):
+    """scipy.signal.find_peaks(x, height, threshold, distance, prominence, width) with scalar lower
+    bounds (scipy/signal/_peak_finding.py `find_peaks`, the order of its condition blocks), built from
+    scipy's own public pieces except the distance step (see _select_by_peak_distance)."""
+    from scipy.signal import find_peaks, peak_prominences, peak_widths
+
+    if distance is not None and distance < 1:
+        raise ValueError("`distance` must be greater or equal to 1")
+    peaks, _ = find_peaks(x)  # local maxima incl. plateau midpoints (_local_maxima_1d)
+    peaks = peaks[x[peaks] >= height]
+    if threshold is not None:
+        lt, rt = x[peaks] - x[peaks - 1], x[peaks] - x[peaks + 1]
+        peaks = peaks[np.minimum(lt, rt) >= threshold]
+    if distance is not None:
+        peaks = peaks[_select_by_peak_distance(peaks, x[peaks], distance)]
+    prom, lb, rb = peak_prominences(x, peaks, wlen=None)
+    ok = prom >= prominence
+    peaks, prom, lb, rb = peaks[ok], prom[ok], lb[ok], rb[ok]
+    widths, _wh, l_ips, r_ips = peak_widths(x, peaks, 0.5, (prom, lb, rb), None)
+    ok = widths >= width
+    return peaks[ok], l_ips[ok], r_ips[ok]
+
+
+def find_peak_hits(records: np.ndarray, wave_pool: np.ndarray, *, use_derivative=True, height=30.0,
+                   distance=2, prominence=0.7, width=4, threshold=None, height_method="minmax",
+                   height_window_extension=4) -> np.ndarray:
+    """peak_finding.py:395-614, records branch (`_process_records_range` + `_find_peaks_in_waveform`
+    + `_calculate_peak_height`), literal per-record loop around find_peaks_staged."""
+    if height_method not in ("minmax", "diff"):
+        raise ValueError(f"不支持的峰高计算方法: {height_method}")
+    rows = []
+    for rec in records:
+        off, n = int(rec["wave_offset"]), int(rec["event_length"])
+        wave = wave_pool[off : off + n]
+        signal = -_normalized_signal_f32(rec, wave, rec["baseline"]).astype(np.float64, copy=False)
+        if signal.size == 0:
+            continue
+        det = np.diff(signal) if use_derivative else signal - 0.0
+        peaks, l_ips, r_ips = find_peaks_staged(det, float(height), threshold, int(distance), float(prominence),
+                                                int(width))
+        dt_ns = int(rec["dt"])
+        for pos, l_ip, r_ip in zip(peaks, l_ips, r_ips):
+            start_idx = max(0, int(np.round(l_ip)))
+            end_idx = min(len(signal) - 1, int(np.round(r_ip)))
+            if height_method == "minmax":
+                ext = max(0, int(height_window_extension))
+                w0, w1 = max(0, start_idx - ext), min(len(signal), end_idx + ext)
+                ph = np.max(signal[w0:w1]) - np.min(signal[w0:w1])
+            else:
+                ph = np.sum(np.diff(-signal)[start_idx:end_idx]) if end_idx > start_idx else 0.0
+            ts = int(int(rec["timestamp"]) + pos * (dt_ns * 1e3))
+            rows.append((int(pos), float(ph), 0.0, float(l_ip), float(r_ip), dt_ns, ts, int(rec["board"]),
+                         int(rec["channel"]), int(rec["record_id"])))
+    return np.array(rows, dtype=HIT_DTYPE) if rows else np.zeros(0, dtype=HIT_DTYPE)

@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE plugins (build container only).
 
 Usage (from any scratch cwd; the reference tree is never written to):
-    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 /root/repo/tests/golden/make_golden.py
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 /root/repo/tests/golden/make_golden.py [name-prefix]
 
 The reference (/root/reference) is imported here and only here.  Every fixture stores the
 inputs (records, wave_pool, options) and the outputs of the reference's own plugin classes:
@@ -39,6 +39,7 @@ from waveform_analysis.core.processing.dtypes import RECORDS_DTYPE  # noqa: E402
 from waveformanalysis_amd import synth  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""  # optional name prefix: regenerate only those fixtures
 
 
 class Ctx:
@@ -73,6 +74,8 @@ class Ctx:
 
 def run_case(name, records, pool, *, filter_cfg=None, hit_cfg=None, bf_cfg=None, wi_cfg=None,
              want=("filtered", "hits_raw", "hits_filt", "bf_raw", "bf_filt", "wi_raw", "wi_filt")):
+    if not name.startswith(ONLY):
+        return
     filter_cfg = dict(filter_cfg or {})
     hit_cfg = dict(hit_cfg or {})
     bf_cfg = dict(bf_cfg or {})
@@ -159,8 +162,29 @@ def ragged_case(seed=7):
     return records, pool
 
 
+def peaks_case(name, records, pool, filtered, configs):
+    """Reference HitFinderPlugin (core/plugins/builtin/cpu/peak_finding.py:49-614, records source)."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.plugins.builtin.cpu.peak_finding import HitFinderPlugin
+
+    out = {"records": records, "wave_pool": pool, "wave_pool_filtered": filtered}
+    cfgs = []
+    for k, cfg in enumerate(configs):
+        ctx = Ctx({"wave_source": "records", **cfg}, {"records": records, "wave_pool": pool,
+                                                        "wave_pool_filtered": filtered})
+        out[f"hit_{k}"] = HitFinderPlugin().compute(ctx, "run")
+        cfgs.append(cfg)
+    out["options_json"] = np.frombuffer(json.dumps(cfgs).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {[len(out[f'hit_{k}']) for k in range(len(configs))]} peaks -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
+    if not name.startswith(ONLY):
+        return
     from waveform_analysis.core.processing.event_grouping import group_hit_windows
 
     out = {"hits": hits, "windows": np.asarray(windows, dtype=np.float64)}
@@ -243,6 +267,33 @@ def main():
                                                             "0:7": {"threshold": 300.0}}},
              bf_cfg={"channel_config": {"0:3": {"fixed_baseline": 8000.0},
                                         "defaults": {"fixed_baseline": None}}})
+
+    # find_peaks-based hit detector (records source), raw and filtered pools, several option sets
+    peak_cfgs = [
+        {},                                                        # defaults: derivative, filtered, h30 d2 p0.7 w4
+        {"use_filtered": False},
+        {"use_derivative": False, "height": 40.0, "width": 3, "prominence": 5.0},
+        {"height": 8.0, "distance": 6, "prominence": 0.5, "width": 1, "height_window_extension": 0},
+        {"use_filtered": False, "height": 12.0, "distance": 1, "prominence": 2.0, "width": 2, "threshold": 1.0},
+        {"height_method": "diff", "height": 20.0, "width": 2},
+        # distance > 2 only on the filtered pool: with equal-height candidates (integer raw samples) scipy's
+        # result depends on the tie order of numpy's unstable argsort, which differs between CPUs
+        {"use_derivative": False, "height": 25.0, "distance": 40, "prominence": 3.0, "width": 2,
+         "height_method": "diff"},
+    ]
+    for preset, cfg, nrec, pol in (("v1725", 14, 48, "unknown"), ("vx2730", 15, 24, "negative")):
+        rec, pool = synth.make_run(nrec, preset, cfg=cfg, polarity=pol)
+        fctx = Ctx({"max_workers": 1}, {"records": rec, "wave_pool": pool})
+        filt = WavePoolFilteredPlugin().compute(fctx, "run")
+        peaks_case(f"peaks_{preset}", rec, pool, filt, peak_cfgs)
+    rec, pool = synth.make_run(32, "v1725", cfg=16)
+    rpos, ppos = flip_positive(rec, pool)
+    fctx = Ctx({"max_workers": 1}, {"records": rpos, "wave_pool": ppos})
+    peaks_case("peaks_positive", rpos, ppos, WavePoolFilteredPlugin().compute(fctx, "run"), peak_cfgs[:3])
+    rec, pool = ragged_case(seed=9)
+    fctx = Ctx({"max_workers": 1}, {"records": rec, "wave_pool": pool})
+    peaks_case("peaks_ragged", rec, pool, WavePoolFilteredPlugin().compute(fctx, "run"),
+               [{"height": 6.0, "width": 1, "prominence": 0.5}, {"use_filtered": False, "height": 6.0, "width": 2}])
 
     # event grouping of threshold hits from a 16-channel run and from a 256-channel run
     for preset, cfg, nrec in (("v1725", 8, 400), ("vx2730", 9, 600)):

@@ -13,13 +13,24 @@ from waveformanalysis_amd.channel_config import per_record_option, scatter_per_r
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names(prefix_exclude=("grouping_",)):
+def case_names(prefix_exclude=("grouping_", "peaks_")):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
     return [n for n in names if not n.startswith(tuple(prefix_exclude))]
 
 
 def grouping_case_names():
     return [n for n in case_names(prefix_exclude=()) if n.startswith("grouping_")]
+
+
+def peaks_case_names():
+    return [n for n in case_names(prefix_exclude=()) if n.startswith("peaks_")]
+
+
+def load_peaks(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["configs"] = json.loads(bytes(d.pop("options_json")).decode())
+    return d
 
 
 def load_grouping(name):

@@ -1,0 +1,127 @@
+"""find_peaks-based `hit` detector (k_find_peaks) through the C ABI vs the reference fixtures and the oracle.
+
+Bar: position / timestamp / ids bit-exact; height / edge_start / edge_end are float32 roundings of the same
+float64 expressions scipy evaluates (same operation order, no contraction) -> compared exactly as well.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import wfa_oracle as O
+from tests import golden_util as G
+from waveformanalysis_amd import _lib, synth
+from waveformanalysis_amd.device import DeviceSession
+from waveformanalysis_amd.plugin_api import SimpleContext
+from waveformanalysis_amd.plugins import HipHitFinderPlugin, HipWavePoolFilteredPlugin
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = DeviceSession(0)
+    yield s
+    s.close()
+
+
+def _run(sess, case, cfg):
+    cfg = dict(cfg)
+    filt = cfg.pop("use_filtered", True)
+    pool = case["wave_pool_filtered"] if filt else case["wave_pool"]
+    sess.upload_pool(pool)
+    sess.upload_records(case["records"], 0.0)
+    return sess.find_peaks(_lib.SRC_F32 if filt else _lib.SRC_RAW, **cfg)
+
+
+@pytest.mark.parametrize("name", G.peaks_case_names())
+def test_session_matches_reference(sess, name):
+    case = G.load_peaks(name)
+    for k, cfg in enumerate(case["configs"]):
+        G.assert_struct_equal(_run(sess, case, cfg), case[f"hit_{k}"], what=f"{name} cfg {k}")
+
+
+@pytest.mark.parametrize("name", G.peaks_case_names())
+def test_plugin_matches_reference(name):
+    case = G.load_peaks(name)
+    for k, cfg in enumerate(case["configs"]):
+        ctx = SimpleContext({"hit": dict(cfg)},
+                            {"records": case["records"], "wave_pool": case["wave_pool"],
+                             "wave_pool_filtered": case["wave_pool_filtered"]},
+                            plugins=[HipHitFinderPlugin()])
+        G.assert_struct_equal(ctx.get_data("run", "hit"), case[f"hit_{k}"], what=f"{name} cfg {k}")
+
+
+def test_plugin_chain_from_raw_pool():
+    """hit <- wave_pool_filtered <- wave_pool, both stages on the GPU."""
+    case = G.load_peaks("peaks_v1725")
+    ctx = SimpleContext({"hit": dict(case["configs"][0])},
+                        {"records": case["records"], "wave_pool": case["wave_pool"]},
+                        plugins=[HipWavePoolFilteredPlugin(), HipHitFinderPlugin()])
+    G.assert_struct_equal(ctx.get_data("run", "hit"), case["hit_0"])
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(),
+    dict(use_derivative=False, height=12.0, prominence=3.0, width=2),
+    dict(height=4.0, prominence=0.5, width=1, distance=7),
+    dict(use_derivative=False, height=8.0, prominence=1.0, width=1, distance=25, threshold=0.5),
+    dict(height=2.0, prominence=0.1, width=1, distance=1, height_window_extension=1),
+    dict(height=3.0, prominence=0.2, width=1, distance=60, height_method="diff"),
+    dict(use_derivative=False, height=5.0, prominence=0.5, width=30, height_method="diff"),
+])
+def test_against_oracle_medium(sess, cfg):
+    rec, pool = synth.make_run(1500, "v1725", cfg=33)
+    filt = O.filter_wave_pool_uniform(pool, 800)
+    for src, p in ((_lib.SRC_F32, filt), (_lib.SRC_RAW, pool)):
+        sess.upload_pool(p)
+        sess.upload_records(rec, 0.0)
+        got = sess.find_peaks(src, **cfg)
+        want = O.find_peak_hits(rec, p, **cfg)
+        assert len(want) > 0
+        G.assert_struct_equal(got, want, what=f"src {src} cfg {cfg}")
+
+
+def test_edge_cases(sess):
+    rec, pool = synth.make_run(8, "v1725", cfg=5)
+    # records too short for any peak, and an empty record list
+    short = rec.copy()
+    short["event_length"] = [0, 1, 2, 3, 4, 5, 800, 800]
+    sess.upload_pool(pool)
+    sess.upload_records(short, 0.0)
+    cfg = dict(height=1.0, prominence=0.1, width=0)
+    G.assert_struct_equal(sess.find_peaks(_lib.SRC_RAW, **cfg), O.find_peak_hits(short, pool, **cfg))
+    sess.upload_records(rec[:0], 0.0)
+    assert len(sess.find_peaks(_lib.SRC_RAW)) == 0
+    sess.upload_records(rec, 0.0)
+    with pytest.raises(ValueError, match="distance"):
+        sess.find_peaks(_lib.SRC_RAW, distance=0)
+    with pytest.raises(ValueError, match="峰高计算方法"):
+        sess.find_peaks(_lib.SRC_RAW, height_method="nope")
+    # no cap on the number of peaks: every local maximum of every record
+    cfg = dict(height=-1e9, prominence=0.0, width=0, height_window_extension=1)
+    got = sess.find_peaks(_lib.SRC_RAW, **cfg)
+    assert len(got) > 100 * len(rec)
+    G.assert_struct_equal(got, O.find_peak_hits(rec, pool, **cfg))
+    # an empty minmax window (ext = 0 around a zero-width peak) is numpy's ValueError in the reference
+    with pytest.raises(ValueError, match="zero-size array"):
+        sess.find_peaks(_lib.SRC_RAW, height=-1e9, prominence=0.0, width=0, height_window_extension=0)
+
+
+def test_plugin_record_id_indirection_and_errors():
+    """peak_finding.py:401-407: the waveform is fetched by record_id, the metadata by row."""
+    case = G.load_peaks("peaks_v1725")
+    rec = case["records"].copy()
+    rec["record_id"] = rec["record_id"][::-1]
+    data = {"records": rec, "wave_pool": case["wave_pool"], "wave_pool_filtered": case["wave_pool_filtered"]}
+    ctx = SimpleContext({"hit": dict(case["configs"][0])}, data, plugins=[HipHitFinderPlugin()])
+    got = ctx.get_data("run", "hit")
+    mixed = rec.copy()
+    for f in ("wave_offset", "event_length", "baseline", "polarity"):
+        mixed[f] = rec[f][rec["record_id"]]
+    cfg = dict(case["configs"][0])
+    cfg.pop("use_filtered", None)
+    G.assert_struct_equal(got, O.find_peak_hits(mixed, case["wave_pool_filtered"], **cfg))
+    with pytest.raises(RuntimeError, match="wave_source"):
+        SimpleContext({"hit": {"wave_source": "st_waveforms"}}, data, plugins=[HipHitFinderPlugin()]).get_data("run", "hit")
+    with pytest.raises(RuntimeError, match="峰高计算方法"):
+        SimpleContext({"hit": {"height_method": "nope"}}, data, plugins=[HipHitFinderPlugin()]).get_data("run", "hit")

@@ -343,7 +343,8 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
-                      &c->hit_desc, &c->bw_scratch, &c->sg.mfma, &c->sg.tab,
+                      &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
+                        &c->peak_cand_state, &c->sg.mfma, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
@@ -377,9 +378,7 @@ int wfa_upload_pool_f32(wfa_ctx* c, const float* pool, int64_t n) {
     int rc = use_device(c);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !pool)) return fail(WFA_E_INVALID, "bad wave_pool_filtered argument");
-    if (c->have_u16 && n != c->pool_n)
-        return fail(WFA_E_INVALID, "wave_pool_filtered has %lld samples, wave_pool has %lld",
-                    (long long)n, (long long)c->pool_n);
+    if (c->have_u16 && n != c->pool_n) c->have_u16 = false;  // a different run: the resident wave_pool is stale
     if ((rc = h2d(c, c->pool_f32, pool, (size_t)n * sizeof(float)))) return rc;
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (!c->have_u16) {
@@ -629,6 +628,112 @@ int wfa_threshold_hits_fill(wfa_ctx* c, void* out_rows, int64_t n_hits) {
     if (n_hits == 0) return WFA_OK;
     if (!out_rows) return fail(WFA_E_INVALID, "out_rows is null");
     WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->hit_out.ptr, (size_t)n_hits * 60, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_find_peaks_count(wfa_ctx* c, int source, int use_derivative, double height, int has_threshold,
+                         double threshold, int32_t distance, double prominence, double width, int height_method,
+                         int32_t ext, int64_t* n_peaks) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, source))) return rc;
+    if (source == WFA_SRC_SG_FUSED) return fail(WFA_E_INVALID, "find_peaks reads wave_pool or a materialised wave_pool_filtered");
+    if (!n_peaks) return fail(WFA_E_INVALID, "n_peaks is null");
+    if (distance < 1) return fail(WFA_E_INVALID, "`distance` must be greater or equal to 1");  // scipy's message
+    if (height_method != WFA_HEIGHT_MINMAX && height_method != WFA_HEIGHT_DIFF)
+        return fail(WFA_E_INVALID, "height_method must be WFA_HEIGHT_MINMAX or WFA_HEIGHT_DIFF");
+    c->n_peaks = -1;
+    if (c->R == 0) { c->n_peaks = 0; *n_peaks = 0; return WFA_OK; }
+    const int64_t R = c->R;
+    if ((rc = c->rec_nhits.ensure(R * sizeof(int32_t)))) return rc;
+    if ((rc = c->rec_out_start.ensure(R * sizeof(int64_t)))) return rc;
+    const int64_t nb = scan_blocks_for(R);
+    if ((rc = c->scan_blocks.ensure((nb + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = c->cursor.ensure(sizeof(unsigned long long)))) return rc;
+    WFA_HIP_CHECK(hipMemsetAsync(c->cursor.ptr, 0, sizeof(unsigned long long), c->stream));
+    PeakParams pp{};
+    pp.use_derivative = use_derivative ? 1 : 0; pp.hmin = height; pp.has_threshold = has_threshold ? 1 : 0;
+    pp.tmin = threshold; pp.distance = distance; pp.pmin = prominence; pp.wmin = width;
+    pp.ext = ext > 0 ? ext : 0; pp.height_diff = height_method == WFA_HEIGHT_DIFF;
+    const PoolView pv = pool_view(c);
+    const RecView rv = rec_view(c);
+    int* err = reinterpret_cast<int*>(c->cursor.ptr);
+    int32_t* counts = c->rec_nhits.as<int32_t>();
+    int64_t* out_start = c->rec_out_start.as<int64_t>();
+    auto scan_total = [&](int64_t* starts, int64_t* total) -> int {
+        WFA_HIP_CHECK(launch_scan(c->stream, counts, R, c->scan_blocks.as<int64_t>(), starts));
+        WFA_HIP_CHECK(hipMemcpyAsync(total, c->scan_blocks.as<int64_t>() + nb, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return WFA_OK;
+    };
+    int64_t total = 0;
+    if (distance <= 2) {
+        // local maxima are at least 2 samples apart: scipy's distance step keeps all of them
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 0, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr, err));
+            if ((rc = t.end("k_find_peaks<count>"))) return rc;
+        }
+        if ((rc = scan_total(out_start, &total))) return rc;
+        if ((rc = c->peak_out.ensure((size_t)total * 48))) return rc;
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 1, pv, rv, pp, nullptr, out_start, c->peak_out.as<uint8_t>(),
+                                        nullptr, nullptr, err));
+        if ((rc = t.end("k_find_peaks<fill>"))) return rc;
+    } else {
+        if ((rc = c->rec_tmp_start.ensure(R * sizeof(int64_t)))) return rc;
+        if ((rc = c->peak_cand_n.ensure(R * sizeof(int32_t)))) return rc;
+        int64_t* cand_start = c->rec_tmp_start.as<int64_t>();
+        int32_t* cand_n = c->peak_cand_n.as<int32_t>();
+        int64_t n_cand = 0;
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 2, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr, err));
+            if ((rc = t.end("k_find_peaks<candidates>"))) return rc;
+        }
+        if ((rc = scan_total(cand_start, &n_cand))) return rc;
+        WFA_HIP_CHECK(hipMemcpyAsync(cand_n, counts, R * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = c->peak_cand_pos.ensure((size_t)n_cand * sizeof(int32_t)))) return rc;
+        if ((rc = c->peak_cand_val.ensure((size_t)n_cand * sizeof(double)))) return rc;
+        if ((rc = c->peak_cand_state.ensure((size_t)n_cand))) return rc;
+        int32_t* cpos = c->peak_cand_pos.as<int32_t>();
+        double* cval = c->peak_cand_val.as<double>();
+        uint8_t* cstate = c->peak_cand_state.as<uint8_t>();
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 3, pv, rv, pp, nullptr, cand_start, nullptr, cpos, cval, err));
+            WFA_HIP_CHECK(launch_peak_select(c->stream, R, cand_n, cand_start, cpos, cval, cstate, distance));
+            WFA_HIP_CHECK(launch_find_peaks_list(c->stream, source, false, pv, rv, pp, cand_n, cand_start, cpos, cstate,
+                                                 counts, nullptr, nullptr, err));
+            if ((rc = t.end("k_find_peaks<candidates+select+count>"))) return rc;
+        }
+        if ((rc = scan_total(out_start, &total))) return rc;
+        if ((rc = c->peak_out.ensure((size_t)total * 48))) return rc;
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_find_peaks_list(c->stream, source, true, pv, rv, pp, cand_n, cand_start, cpos, cstate, nullptr,
+                                             out_start, c->peak_out.as<uint8_t>(), err));
+        if ((rc = t.end("k_find_peaks_list<fill>"))) return rc;
+    }
+    int flag = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&flag, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (flag)  // numpy's message for np.max of the empty height window (peak_finding.py:606)
+        return fail(WFA_E_INVALID, "zero-size array to reduction operation maximum which has no identity");
+    c->n_peaks = total;
+    *n_peaks = total;
+    return WFA_OK;
+}
+
+int wfa_find_peaks_fill(wfa_ctx* c, void* out_rows, int64_t n_peaks) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (c->n_peaks < 0) return fail(WFA_E_STATE, "no find_peaks pass has been run");
+    if (n_peaks != c->n_peaks)
+        return fail(WFA_E_INVALID, "caller expects %lld rows, the pass produced %lld", (long long)n_peaks, (long long)c->n_peaks);
+    if (n_peaks == 0) return WFA_OK;
+    if (!out_rows) return fail(WFA_E_INVALID, "out_rows is null");
+    WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->peak_out.ptr, (size_t)n_peaks * 48, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return WFA_OK;
 }

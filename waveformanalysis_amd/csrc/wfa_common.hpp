@@ -102,6 +102,9 @@ struct wfa_ctx {
     int64_t n_hits = -1;
 
     wfa::DevBuf out_rows;  // per-record feature rows
+    wfa::DevBuf peak_out;  // HIT_DTYPE rows of the last find_peaks pass
+    int64_t n_peaks = -1;
+    wfa::DevBuf peak_cand_n, peak_cand_pos, peak_cand_val, peak_cand_state;  // distance > 2: candidate lists
     wfa::DevBuf bw_scratch;  // float64 forward pass of sosfiltfilt, [sample][record-in-batch]
 
     // profiling

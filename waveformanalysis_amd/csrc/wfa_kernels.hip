@@ -2202,6 +2202,317 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
 }
 
 // =============================================================================================
+// K8: find_peaks-based hit detector  (peak_finding.py:395-614, records branch; scipy.signal.find_peaks)
+// =============================================================================================
+// One lane per record executes scipy's algorithm literally on the detection signal
+//   det = diff(signal)  (use_derivative)  or  signal,   signal = -rv.signals(id) as float64 of float32
+// in scipy's order: local maxima with plateaus (_local_maxima_1d, streamed) -> height -> threshold ->
+// distance (_select_by_peak_distance) -> prominence (_peak_prominences) -> width at half prominence
+// (_peak_widths, interpolated intersection points).  Every pass runs twice (count, then fill at the
+// scanned offsets) so rows come out in (record, position) order without a gather and nothing is capped.
+//   distance <= 2 (the default; a no-op for local maxima): candidates are consumed as they stream by.
+//   distance  > 2: candidates (position, value) go to a global list, k_peak_select marks the survivors in
+//                  scipy's priority order, then the later stages walk the list.
+constexpr int kPeakBlock = 128;
+constexpr int kPeakErrEmptyWindow = 2;
+
+template <int SRC>
+struct SignalAt {
+    const uint16_t* xu;
+    const float* xf;
+    float b32;
+    bool positive;
+    int use_derivative;
+    int L, n;  // samples in the record, samples of the detection signal
+    __device__ __forceinline__ double sig(int i) const {
+        const float w = SRC == WFA_SRC_RAW ? (float)xu[i] : xf[i];
+        const float d = w - b32;             // records_view.py:87-100 (float32)
+        return (double)(positive ? d : -d);  // signal = -normalized
+    }
+    __device__ __forceinline__ double det(int i) const {
+        return use_derivative ? sig(i + 1) - sig(i) : sig(i) - 0.0;
+    }
+    __device__ __forceinline__ void bind(const PoolView& pool, const RecView& rec, int64_t r, int use_deriv) {
+        const int64_t off = rec.off[r];
+        xu = pool.u16 ? pool.u16 + off : nullptr;
+        xf = pool.f32 ? pool.f32 + off : nullptr;
+        b32 = (float)rec.baseline[r];
+        positive = rec.pol[r] == WFA_POL_POSITIVE;
+        use_derivative = use_deriv;
+        L = rec.len[r];
+        n = use_deriv ? L - 1 : L;
+    }
+};
+
+// numpy pairwise_sum (umath/loops_utils.h.src) of f(a) .. f(a+n-1), float64
+template <typename F>
+__device__ double np_pairwise_leaf(const F& f, int a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += f(a + i);
+        return res;
+    }
+    double r0 = f(a), r1 = f(a + 1), r2 = f(a + 2), r3 = f(a + 3), r4 = f(a + 4), r5 = f(a + 5), r6 = f(a + 6),
+           r7 = f(a + 7);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += f(a + i); r1 += f(a + i + 1); r2 += f(a + i + 2); r3 += f(a + i + 3);
+        r4 += f(a + i + 4); r5 += f(a + i + 5); r6 += f(a + i + 6); r7 += f(a + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += f(a + i);
+    return res;
+}
+
+template <typename F>
+__device__ double np_pairwise_sum(const F& f, int a0, int n0) {
+    if (n0 <= 128) return np_pairwise_leaf(f, a0, n0);
+    constexpr int kDepth = 28;
+    int sa[kDepth], sn[kDepth], sp[kDepth];
+    double sl[kDepth];
+    int top = 0;
+    sa[0] = a0; sn[0] = n0; sp[0] = 0;
+    double ret = 0.0;
+    while (top >= 0) {
+        const int a = sa[top], n = sn[top];
+        if (n > 128) {  // descend left
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            sp[top] = 1;
+            ++top;
+            sa[top] = a; sn[top] = n2; sp[top] = 0;
+            continue;
+        }
+        ret = np_pairwise_leaf(f, a, n);
+        --top;
+        while (top >= 0) {
+            if (sp[top] == 1) {  // left half done: keep it, descend right
+                sl[top] = ret;
+                sp[top] = 2;
+                int n2 = sn[top] / 2;
+                n2 -= n2 % 8;
+                const int pa = sa[top], pn = sn[top];
+                ++top;
+                sa[top] = pa + n2; sn[top] = pn - n2; sp[top] = 0;
+                break;
+            }
+            ret = sl[top] + ret;
+            --top;
+        }
+    }
+    return ret;
+}
+
+// prominence + width of one candidate; false when it fails `prominence` or `width`
+template <int SRC>
+__device__ bool peak_passes(const SignalAt<SRC>& S, int peak, const PeakParams& pp, double& left_ip, double& right_ip) {
+    const int n = S.n;
+    const double xp = S.det(peak);
+    int i = peak, left_base = peak, right_base = peak;
+    double left_min = xp, right_min = xp;
+    while (0 <= i) {
+        const double v = S.det(i);
+        if (!(v <= xp)) break;
+        if (v < left_min) { left_min = v; left_base = i; }
+        --i;
+    }
+    i = peak;
+    while (i <= n - 1) {
+        const double v = S.det(i);
+        if (!(v <= xp)) break;
+        if (v < right_min) { right_min = v; right_base = i; }
+        ++i;
+    }
+    const double prom = xp - (left_min > right_min ? left_min : right_min);
+    if (!(prom >= pp.pmin)) return false;
+    const double hgt = xp - prom * 0.5;  // rel_height = 0.5
+    i = peak;
+    while (left_base < i && hgt < S.det(i)) --i;
+    left_ip = (double)i;
+    {
+        const double xi = S.det(i);
+        if (xi < hgt) left_ip += (hgt - xi) / (S.det(i + 1) - xi);
+    }
+    i = peak;
+    while (i < right_base && hgt < S.det(i)) ++i;
+    right_ip = (double)i;
+    {
+        const double xi = S.det(i);
+        if (xi < hgt) right_ip -= (hgt - xi) / (S.det(i - 1) - xi);
+    }
+    return right_ip - left_ip >= pp.wmin;
+}
+
+// HIT_DTYPE row of one accepted peak (peak_finding.py:508-563 and _calculate_peak_height 567-614)
+template <int SRC>
+__device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64_t r, int peak, double left_ip,
+                               double right_ip, const PeakParams& pp, uint32_t* row, int* err) {
+    const int L = S.L;
+    int start_idx = (int)rint(left_ip), end_idx = (int)rint(right_ip);  // np.round: half to even
+    if (start_idx < 0) start_idx = 0;
+    if (end_idx > L - 1) end_idx = L - 1;
+    double ph;
+    if (pp.height_diff) {
+        ph = 0.0;
+        if (end_idx > start_idx)
+            ph = np_pairwise_sum([&](int q) { return (-S.sig(q + 1)) - (-S.sig(q)); }, start_idx, end_idx - start_idx);
+    } else {
+        int w0 = start_idx - pp.ext, w1 = end_idx + pp.ext;
+        if (w0 < 0) w0 = 0;
+        if (w1 > L) w1 = L;
+        if (w1 <= w0) atomicExch(err, kPeakErrEmptyWindow);  // numpy: max of a zero-size array
+        double vmax = -__builtin_huge_val(), vmin = __builtin_huge_val();
+        for (int q = w0; q < w1; ++q) {
+            const double v = S.sig(q);
+            vmax = v > vmax ? v : vmax;
+            vmin = v < vmin ? v : vmin;
+        }
+        ph = vmax - vmin;
+    }
+    const int dt_ns = rec.dt[r];
+    put_i64(row, 0, (int64_t)peak);
+    put_f32(row, 2, (float)ph);
+    put_f32(row, 3, 0.0f);
+    put_f32(row, 4, (float)left_ip);
+    put_f32(row, 5, (float)right_ip);
+    row[6] = (uint32_t)dt_ns;
+    put_i64(row, 7, (int64_t)((double)rec.ts[r] + (double)peak * ((double)dt_ns * 1e3)));
+    row[9] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
+    put_i64(row, 10, rec.rid[r]);
+}
+
+// Streaming _local_maxima_1d + height + threshold; calls on_peak(position, value) per candidate in order.
+template <int SRC, typename F>
+__device__ void scan_candidates(const SignalAt<SRC>& S, const PeakParams& pp, const F& on_peak) {
+    const int n = S.n;
+    if (n < 3) return;
+    bool have = false;
+    int c_start = 0;
+    double c_val = 0.0;
+    double x_prev = S.det(0);
+    double s_prev = 0.0;
+    if (S.use_derivative) s_prev = S.sig(1);
+    for (int i = 1; i < n; ++i) {
+        double x;
+        if (S.use_derivative) {  // one new sample per step
+            const double s_next = S.sig(i + 1);
+            x = s_next - s_prev;
+            s_prev = s_next;
+        } else {
+            x = S.sig(i) - 0.0;
+        }
+        if (have) {
+            if (x < c_val) {
+                const int peak = (c_start + i - 1) / 2;  // midpoint of the plateau
+                bool keep = c_val >= pp.hmin;
+                if (keep && pp.has_threshold) {
+                    const double lt = c_val - S.det(peak - 1), rt = c_val - S.det(peak + 1);
+                    keep = (lt < rt ? lt : rt) >= pp.tmin;
+                }
+                if (keep) on_peak(peak, c_val);
+                have = false;
+            } else if (x > c_val) {
+                c_start = i; c_val = x;  // a higher step starts a new candidate
+            }
+        } else if (x_prev < x && i < n - 1) {
+            have = true; c_start = i; c_val = x;
+        }
+        x_prev = x;
+    }
+}
+
+// MODE 0/1: count / fill final rows straight from the stream (distance <= 2)
+// MODE 2/3: count / fill the candidate list (distance > 2)
+template <int SRC, int MODE>
+__global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecView rec, PeakParams pp,
+                                                           int32_t* __restrict__ counts,
+                                                           const int64_t* __restrict__ out_start,
+                                                           uint8_t* __restrict__ out, int32_t* __restrict__ cand_pos,
+                                                           double* __restrict__ cand_val, int* __restrict__ err) {
+    const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    if (r >= rec.R) return;
+    SignalAt<SRC> S;
+    S.bind(pool, rec, r, pp.use_derivative);
+    int n_out = 0;
+    if (S.L > 0) {
+        const int64_t base = (MODE == 1 || MODE == 3) ? out_start[r] : 0;
+        scan_candidates(S, pp, [&](int peak, double val) {
+            if (MODE == 2) { ++n_out; return; }
+            if (MODE == 3) {
+                cand_pos[base + n_out] = peak;
+                cand_val[base + n_out] = val;
+                ++n_out;
+                return;
+            }
+            double l_ip, r_ip;
+            if (!peak_passes(S, peak, pp, l_ip, r_ip)) return;
+            if (MODE == 1)
+                write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err);
+            ++n_out;
+        });
+    }
+    if (MODE == 0 || MODE == 2) counts[r] = n_out;
+}
+
+// _select_by_peak_distance on the candidate list of each record: visit candidates by descending value (ties: the
+// later candidate first == a stable ascending argsort read backwards) and drop the not-yet-dropped neighbours
+// closer than `distance`.  state: 1 = kept & unvisited, 2 = kept & visited, 0 = dropped.
+__global__ __launch_bounds__(kPeakBlock) void k_peak_select(int64_t R, const int32_t* __restrict__ counts,
+                                                            const int64_t* __restrict__ cand_start,
+                                                            const int32_t* __restrict__ cand_pos,
+                                                            const double* __restrict__ cand_val,
+                                                            uint8_t* __restrict__ state, int distance) {
+    const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    if (r >= R) return;
+    const int K = counts[r];
+    const int64_t b = cand_start[r];
+    for (int k = 0; k < K; ++k) state[b + k] = 1;
+    for (;;) {
+        int best = -1;
+        double bv = 0.0;
+        for (int k = 0; k < K; ++k) {
+            if (state[b + k] != 1) continue;
+            const double v = cand_val[b + k];
+            if (best < 0 || v >= bv) { best = k; bv = v; }
+        }
+        if (best < 0) break;
+        state[b + best] = 2;
+        const int pj = cand_pos[b + best];
+        for (int k = best - 1; k >= 0 && pj - cand_pos[b + k] < distance; --k) state[b + k] = 0;
+        for (int k = best + 1; k < K && cand_pos[b + k] - pj < distance; ++k) state[b + k] = 0;
+    }
+}
+
+template <int SRC, bool FILL>
+__global__ __launch_bounds__(kPeakBlock) void k_find_peaks_list(PoolView pool, RecView rec, PeakParams pp,
+                                                                const int32_t* __restrict__ cand_count,
+                                                                const int64_t* __restrict__ cand_start,
+                                                                const int32_t* __restrict__ cand_pos,
+                                                                const uint8_t* __restrict__ state,
+                                                                int32_t* __restrict__ counts,
+                                                                const int64_t* __restrict__ out_start,
+                                                                uint8_t* __restrict__ out, int* __restrict__ err) {
+    const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    if (r >= rec.R) return;
+    SignalAt<SRC> S;
+    S.bind(pool, rec, r, pp.use_derivative);
+    const int K = cand_count[r];
+    const int64_t b = cand_start[r];
+    const int64_t base = FILL ? out_start[r] : 0;
+    int n_out = 0;
+    for (int k = 0; k < K; ++k) {
+        if (!state[b + k]) continue;
+        const int peak = cand_pos[b + k];
+        double l_ip, r_ip;
+        if (!peak_passes(S, peak, pp, l_ip, r_ip)) continue;
+        if (FILL)
+            write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err);
+        ++n_out;
+    }
+    if (!FILL) counts[r] = n_out;
+}
+
+// =============================================================================================
 // K3: Butterworth band-pass, scipy.signal.sosfiltfilt  (filtering.py:84-101,198-224)
 // =============================================================================================
 // sosfiltfilt is a recursive filter: strictly sequential along a record, independent across records,
@@ -2397,6 +2708,51 @@ hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecVie
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_sosfiltfilt, dim3(grid), dim3(kBlock), 0, st, pool, rec, sp, r_begin, r_end, scratch,
                        batch_stride, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_find_peaks(hipStream_t st, int source, int mode, const PoolView& pool, const RecView& rec,
+                             const PeakParams& pp, int32_t* counts, const int64_t* out_start, uint8_t* out,
+                             int32_t* cand_pos, double* cand_val, int* err) {
+    if (rec.R == 0) return hipSuccess;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((rec.R + kPeakBlock - 1) / kPeakBlock);
+#define WFA_PK(SRC, M) \
+    hipLaunchKernelGGL((k_find_peaks<SRC, M>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, counts, out_start, out, cand_pos, cand_val, err)
+#define WFA_PK_SRC(M) do { if (source == WFA_SRC_RAW) WFA_PK(WFA_SRC_RAW, M); else WFA_PK(WFA_SRC_F32, M); } while (0)
+    switch (mode) {
+        case 0: WFA_PK_SRC(0); break;
+        case 1: WFA_PK_SRC(1); break;
+        case 2: WFA_PK_SRC(2); break;
+        case 3: WFA_PK_SRC(3); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef WFA_PK_SRC
+#undef WFA_PK
+    return hipGetLastError();
+}
+
+hipError_t launch_peak_select(hipStream_t st, int64_t R, const int32_t* counts, const int64_t* cand_start,
+                              const int32_t* cand_pos, const double* cand_val, uint8_t* state, int distance) {
+    if (R == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((R + kPeakBlock - 1) / kPeakBlock);
+    hipLaunchKernelGGL(k_peak_select, dim3(grid), dim3(kPeakBlock), 0, st, R, counts, cand_start, cand_pos, cand_val,
+                       state, distance);
+    return hipGetLastError();
+}
+
+hipError_t launch_find_peaks_list(hipStream_t st, int source, bool fill, const PoolView& pool, const RecView& rec,
+                                  const PeakParams& pp, const int32_t* cand_count, const int64_t* cand_start,
+                                  const int32_t* cand_pos, const uint8_t* state, int32_t* counts,
+                                  const int64_t* out_start, uint8_t* out, int* err) {
+    if (rec.R == 0) return hipSuccess;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((rec.R + kPeakBlock - 1) / kPeakBlock);
+#define WFA_PL(SRC, F) \
+    hipLaunchKernelGGL((k_find_peaks_list<SRC, F>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, cand_count, cand_start, cand_pos, state, counts, out_start, out, err)
+    if (source == WFA_SRC_RAW) { if (fill) WFA_PL(WFA_SRC_RAW, true); else WFA_PL(WFA_SRC_RAW, false); }
+    else { if (fill) WFA_PL(WFA_SRC_F32, true); else WFA_PL(WFA_SRC_F32, false); }
+#undef WFA_PL
     return hipGetLastError();
 }
 

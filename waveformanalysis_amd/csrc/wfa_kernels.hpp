@@ -86,6 +86,19 @@ struct RowParams {
     int32_t fast_halo;  // SG half window when the integer row kernel may be used, else 0
 };
 
+// find_peaks-based hit detector (k_find_peaks): scalar lower bounds only, as the reference plugin passes them
+struct PeakParams {
+    int use_derivative;
+    double hmin;
+    int has_threshold;
+    double tmin;
+    int distance;
+    double pmin;
+    double wmin;
+    int ext;
+    int height_diff;  // 1: height_method 'diff', 0: 'minmax'
+};
+
 struct FeatParams {
     int64_t h0, h1, a0, a1;
     int h_has_end, a_has_end;
@@ -112,6 +125,16 @@ hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t*
 hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecView& rec, int n_sections,
                               const double* sos, const double* zi, int edge, int64_t r_begin, int64_t r_end,
                               double* scratch, int64_t batch_stride, float* out);
+// mode 0/1: count/fill final rows from the stream (distance <= 2); 2/3: count/fill the candidate list
+hipError_t launch_find_peaks(hipStream_t st, int source, int mode, const PoolView& pool, const RecView& rec,
+                             const PeakParams& pp, int32_t* counts, const int64_t* out_start, uint8_t* out,
+                             int32_t* cand_pos, double* cand_val, int* err);
+hipError_t launch_peak_select(hipStream_t st, int64_t R, const int32_t* counts, const int64_t* cand_start,
+                              const int32_t* cand_pos, const double* cand_val, uint8_t* state, int distance);
+hipError_t launch_find_peaks_list(hipStream_t st, int source, bool fill, const PoolView& pool, const RecView& rec,
+                                  const PeakParams& pp, const int32_t* cand_count, const int64_t* cand_start,
+                                  const int32_t* cand_pos, const uint8_t* state, int32_t* counts,
+                                  const int64_t* out_start, uint8_t* out, int* err);
 bool sg_mask_supported(const SgParams& sg);
 hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);

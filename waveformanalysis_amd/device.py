@@ -16,6 +16,7 @@ import numpy as np
 from . import _lib
 from .dtypes import (
     BASIC_FEATURES_DTYPE,
+    HIT_DTYPE,
     THRESHOLD_HIT_DTYPE,
     WAVEFORM_WIDTH_INTEGRAL_DTYPE,
 )
@@ -102,7 +103,10 @@ class DeviceSession:
         self.n_samples = int(wave_pool.size)
 
     def upload_filtered_pool(self, pool_f32: np.ndarray) -> None:
+        """wave_pool_filtered as the float32 twin of the resident wave_pool (same sample count)."""
         arr = np.ascontiguousarray(pool_f32, dtype=np.float32)
+        if self.n_samples and arr.size != self.n_samples:
+            raise ValueError(f"wave_pool_filtered has {arr.size} samples, wave_pool has {self.n_samples}")
         _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
 
     def upload_records(self, records: np.ndarray, thresholds: np.ndarray | float = 10.0) -> None:
@@ -186,6 +190,21 @@ class DeviceSession:
             self._h, int(baseline_window[0]), int(baseline_window[1]), int(left_extension),
             int(right_extension), int(max_len), C.byref(n)))
         return self._fill_hits(int(n.value)) if download else int(n.value)
+
+    def find_peaks(self, source: int = _lib.SRC_F32, use_derivative: bool = True, height: float = 30.0,
+                   distance: int = 2, prominence: float = 0.7, width: float = 4, threshold: float | None = None,
+                   height_method: str = "minmax", height_window_extension: int = 4) -> np.ndarray:
+        """find_peaks-based hit detector (HitFinderPlugin, records source) -> HIT_DTYPE rows."""
+        if height_method not in ("minmax", "diff"):
+            raise ValueError(f"不支持的峰高计算方法: {height_method}")  # peak_finding.py:612
+        n = C.c_int64(0)
+        _lib.check(self._lib.wfa_find_peaks_count(
+            self._h, int(source), int(bool(use_derivative)), float(height), int(threshold is not None),
+            float(threshold or 0.0), int(distance), float(prominence), float(width),
+            1 if height_method == "diff" else 0, int(height_window_extension), C.byref(n)))
+        out = np.empty(int(n.value), dtype=HIT_DTYPE)
+        _lib.check(self._lib.wfa_find_peaks_fill(self._h, _ptr(out), int(n.value)))
+        return out
 
     def basic_features(self, source: int = _lib.SRC_RAW, height_range=(40, 90), area_range=(0, None),
                        fixed_baseline: np.ndarray | None = None) -> np.ndarray:

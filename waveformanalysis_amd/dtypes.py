@@ -81,6 +81,23 @@ WAVEFORM_WIDTH_INTEGRAL_DTYPE = np.dtype(
     ]
 )
 
+# HIT_DTYPE of the find_peaks-based detector (reference: cpu/peak_finding.py:30-43, 48 B)
+HIT_DTYPE = np.dtype(
+    [
+        ("position", "i8"),
+        ("height", "f4"),
+        ("integral", "f4"),
+        ("edge_start", "f4"),
+        ("edge_end", "f4"),
+        ("dt", "i4"),
+        ("timestamp", "i8"),
+        ("board", "i2"),
+        ("channel", "i2"),
+        ("record_id", "i8"),
+    ]
+)
+
+assert HIT_DTYPE.itemsize == 48
 assert RECORDS_DTYPE.itemsize == 102
 assert THRESHOLD_HIT_DTYPE.itemsize == 60
 assert BASIC_FEATURES_DTYPE.itemsize == 36
@@ -91,4 +108,5 @@ __all__ = [
     "THRESHOLD_HIT_DTYPE",
     "BASIC_FEATURES_DTYPE",
     "WAVEFORM_WIDTH_INTEGRAL_DTYPE",
+    "HIT_DTYPE",
 ]

@@ -6,6 +6,7 @@ with ``ctx.register(p, allow_override=True)`` to replace the CPU plugins of the 
 """
 
 from .basic_features import HipBasicFeaturesPlugin
+from .hit_finder import HipHitFinderPlugin
 from .hit_grouped import HipHitGroupedPlugin
 from .threshold_hit import HipThresholdHitPlugin
 from .wave_pool_filtered import HipWavePoolFilteredPlugin
@@ -14,8 +15,8 @@ from .width_integral import HipWaveformWidthIntegralPlugin
 
 def hip_default():
     return [HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
-            HipWaveformWidthIntegralPlugin(), HipHitGroupedPlugin()]
+            HipWaveformWidthIntegralPlugin(), HipHitGroupedPlugin(), HipHitFinderPlugin()]
 
 
 __all__ = ["HipWavePoolFilteredPlugin", "HipThresholdHitPlugin", "HipBasicFeaturesPlugin",
-           "HipWaveformWidthIntegralPlugin", "HipHitGroupedPlugin", "hip_default"]
+           "HipWaveformWidthIntegralPlugin", "HipHitGroupedPlugin", "HipHitFinderPlugin", "hip_default"]
