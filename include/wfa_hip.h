@@ -50,6 +50,9 @@ extern "C" {
 #define WFA_POL_UNKNOWN 0
 #define WFA_POL_NEGATIVE 1
 #define WFA_POL_POSITIVE 2
+/* dense st_waveforms rule of BasicFeaturesPlugin (basic_features.py:243-262): wave-based formulas, positive sign;
+ * every other stage treats it like WFA_POL_UNKNOWN */
+#define WFA_POL_POSITIVE_WAVE 3
 
 typedef struct wfa_ctx wfa_ctx;
 
@@ -106,6 +109,15 @@ int wfa_set_sg_plan(wfa_ctx* ctx, int window, int polyorder, const double* tab,
  * Writes the device-resident baseline column when update_records != 0; out may be NULL. */
 int wfa_baseline_mean(wfa_ctx* ctx, int32_t start, int32_t end, int update_records, double* out);
 
+/* Filter channel groups with different settings into ONE wave_pool_filtered (reference: per-channel
+ * filter configs of build_filter_batches, cpu/filtering.py:339-374).  keep = 0 (default): wfa_savgol /
+ * wfa_sosfiltfilt zero the whole output first (gaps stay 0.0, records.py:382) and then write the uploaded
+ * records' slices.  keep = 1: the output is left as it is and only the uploaded records' slices are written. */
+int wfa_filter_keep_output(wfa_ctx* ctx, int keep);
+
+/* Copy the resident float32 pool (wave_pool_filtered as built or uploaded) to the host; n_samples must match. */
+int wfa_download_pool_f32(wfa_ctx* ctx, float* out, int64_t n_samples);
+
 /* K2 wave_pool_filtered: float32 pool aligned to wave_pool, gaps 0.0
  * (reference: records.py:368-438, filtering.py:377-407).  The result stays resident as the
  * WFA_SRC_F32 pool; out may be NULL. */
@@ -153,6 +165,19 @@ int wfa_find_peaks_fill(wfa_ctx* ctx, void* out_rows, int64_t n_peaks);
 int wfa_basic_features(wfa_ctx* ctx, int source, int64_t height_start, int64_t height_end,
                        int height_has_end, int64_t area_start, int64_t area_end, int area_has_end,
                        const double* fixed_baseline, void* out_rows);
+
+/* K10 rise/fall/total width per hit on dense waveform rows (reference: cpu/waveform_width.py:205-374).
+ * The resident pool is the row-major (n_rows x row_length) wave matrix of st_waveforms (source WFA_SRC_RAW,
+ * non-negative int16 ADC codes viewed as uint16) or filtered_waveforms (WFA_SRC_F32).  Per hit: position and
+ * the row it refers to (row_index < 0: no such row, hit skipped).  out: WAVEFORM_WIDTH_DTYPE rows (56 B) with the
+ * six width fields, peak_position and peak_height filled, the id fields zero (the caller copies them from the
+ * hit table); valid[i] = 0 where the reference drops the hit (position past the row, peak value <= 0).
+ * Arithmetic follows numpy's promotion rules for the source dtype (float64 for int16 rows, float32 for
+ * float32 rows incl. its mixed python-float cases), so the float fields are bit-exact. */
+int wfa_waveform_width(wfa_ctx* ctx, int source, int64_t n_hits, const int64_t* position,
+                       const int64_t* row_index, int64_t n_rows, int32_t row_length, double rise_low,
+                       double rise_high, double fall_high, double fall_low, double sampling_rate,
+                       int interpolation, void* out_rows, uint8_t* valid);
 
 /* K6 integral-quantile width (reference: waveform_width_integral.py:166-227).
  * out: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B). */

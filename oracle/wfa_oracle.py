@@ -490,3 +490,175 @@ def find_peak_hits(records: np.ndarray, wave_pool: np.ndarray, *, use_derivative
             rows.append((int(pos), float(ph), 0.0, float(l_ip), float(r_ip), dt_ns, ts, int(rec["board"]),
                          int(rec["channel"]), int(rec["record_id"])))
     return np.array(rows, dtype=HIT_DTYPE) if rows else np.zeros(0, dtype=HIT_DTYPE)
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense (st_waveforms / filtered_waveforms) branches, waveform_width, s1_s2
+# ------------------------------------------------------------------------------------------------
+WAVEFORM_WIDTH_DTYPE = np.dtype(
+    [("rise_time", "f4"), ("fall_time", "f4"), ("total_width", "f4"), ("rise_time_samples", "f4"),
+     ("fall_time_samples", "f4"), ("total_width_samples", "f4"), ("peak_position", "i8"), ("peak_height", "f4"),
+     ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"), ("record_id", "i8")]
+)
+S1_S2_CLASSIFIER_DTYPE = np.dtype(
+    [("label", "i1"), ("width_ns", "f4"), ("width_samples", "f4"), ("height", "f4"), ("area", "f4"),
+     ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"), ("record_id", "i8"), ("peak_position", "i8")]
+)
+
+
+def filtered_waveforms_dense(st: np.ndarray, cfg_of_channel) -> np.ndarray:
+    """filtering.py:444-536: each hardware channel's rows are filtered as ONE 2-D float32 batch (axis=-1).
+
+    cfg_of_channel(board, channel) -> kwargs of apply_filter_core.  Returns the float32 wave matrix."""
+    waves = st["wave"]
+    out = np.empty(waves.shape, dtype=np.float32)
+    boards = st["board"] if "board" in st.dtype.names else np.zeros(len(st), dtype=np.int16)
+    keys = sorted(set(zip(boards.tolist(), st["channel"].tolist())))
+    for b, c in keys:
+        rows = np.flatnonzero((boards == b) & (st["channel"] == c))
+        out[rows] = apply_filter_core(np.asarray(waves[rows], dtype=np.float32), **cfg_of_channel(b, c))
+    return out
+
+
+def basic_features_dense(data: np.ndarray, *, height_range=(40, 90), area_range=(0, None),
+                         fixed_baseline=None) -> np.ndarray:
+    """basic_features.py:197-278 (st_waveforms / filtered_waveforms): whole rows, wave-based formulas for every
+    polarity, sign flipped only for the literal "positive"."""
+    p0, p1 = height_range
+    c0, c1 = area_range
+    out = np.zeros(len(data), dtype=BASIC_FEATURES_DTYPE)
+    names = data.dtype.names
+    for i in range(len(data)):
+        wave = data["wave"][i]
+        b = float(data["baseline"][i])
+        if fixed_baseline is not None and not np.isnan(fixed_baseline[i]):
+            b = float(fixed_baseline[i])
+        positive = "polarity" in names and str(data["polarity"][i]) == "positive"
+        wp = wave[p0:p1]
+        if wp.size:
+            lo, hi = float(np.min(wp)), float(np.max(wp))
+            out["height"][i] = (hi - b) if positive else (b - lo)
+            out["amp"][i] = hi - lo
+        wc = wave[c0:c1].astype(np.float64, copy=False)
+        if wc.size:
+            out["area"][i] = float(np.sum(wc - b)) if positive else float(np.sum(b - wc))
+        if wave.size > 1:
+            out["max_abs_diff"][i] = float(np.max(np.abs(np.diff(wave.astype(np.float64, copy=False)))))
+    out["timestamp"] = data["timestamp"]
+    out["board"] = data["board"] if "board" in names else 0
+    out["channel"] = data["channel"] if "channel" in names else 0
+    out["event_index"] = np.arange(len(data))
+    return out
+
+
+def _first_crossing(seg: np.ndarray, level, rising: bool, interpolate: bool):
+    """waveform_width.py:332-374: first sample at/over (rising) or at/under (falling) `level`, refined by the
+    straight line through its left neighbour.  Keeps numpy's scalar types exactly as the reference's
+    expressions produce them (python float for the un-refined index)."""
+    if seg.size == 0:
+        return None
+    hit = np.flatnonzero(seg >= level) if rising else np.flatnonzero(seg <= level)
+    if hit.size == 0:
+        return None
+    k = hit[0]
+    if not interpolate or k == 0:
+        return float(k)
+    left, right = seg[k - 1], seg[k]
+    if abs(right - left) < 1e-10:
+        return float(k)
+    return float(k - 1) + (level - left) / (right - left)
+
+
+def waveform_width(hits: np.ndarray, waveform_data: np.ndarray, *, rise_low=0.1, rise_high=0.9, fall_high=0.9,
+                   fall_low=0.1, sampling_rate=0.5, interpolation=True) -> np.ndarray:
+    """waveform_width.py:139-330, literal per-hit loop (row found by the FIRST matching record_id)."""
+    rows = []
+    has_rid = "record_id" in (waveform_data.dtype.names or ())
+    for h in hits:
+        rid = int(h["record_id"]) if "record_id" in h.dtype.names else int(h["event_index"])
+        if has_rid:
+            where = np.flatnonzero(waveform_data["record_id"] == rid)
+            if where.size == 0:
+                continue
+            wave = waveform_data[int(where[0])]["wave"]
+        else:
+            if not 0 <= rid < len(waveform_data):
+                continue
+            wave = waveform_data[rid]["wave"]
+        pos = h["position"]
+        corrected = wave - np.mean(wave[:50])
+        if pos >= len(corrected):
+            continue
+        top = corrected[pos]
+        if top <= 0:
+            continue
+        before, after = corrected[:pos], corrected[pos:]
+        r_lo = _first_crossing(before, top * rise_low, True, interpolation)
+        r_hi = _first_crossing(before, top * rise_high, True, interpolation)
+        f_hi = _first_crossing(after, top * fall_high, False, interpolation)
+        f_lo = _first_crossing(after, top * fall_low, False, interpolation)
+        rise_s = rise_t = fall_s = fall_t = tot_s = tot_t = 0.0
+        if r_lo is not None and r_hi is not None:
+            rise_s = r_hi - r_lo
+            rise_t = rise_s / sampling_rate
+        if f_hi is not None and f_lo is not None:
+            f_hi = f_hi + pos  # np.int64 position: promotes to float64
+            f_lo = f_lo + pos
+            fall_s = f_lo - f_hi
+            fall_t = fall_s / sampling_rate
+        if r_lo is not None and f_lo is not None:
+            tot_s = f_lo - r_lo
+            tot_t = tot_s / sampling_rate
+        rows.append((float(rise_t), float(fall_t), float(tot_t), float(rise_s), float(fall_s), float(tot_s), int(pos),
+                     float(top), int(h["timestamp"]), int(h["board"]) if "board" in h.dtype.names else 0,
+                     int(h["channel"]), rid))
+    return np.array(rows, dtype=WAVEFORM_WIDTH_DTYPE) if rows else np.zeros(0, dtype=WAVEFORM_WIDTH_DTYPE)
+
+
+def s1_s2_classify(widths: np.ndarray, features: np.ndarray, *, width_unit="ns", s1_width_range=None,
+                   s2_width_range=None, s1_area_range=None, s2_area_range=None, s1_height_range=None,
+                   s2_height_range=None, conflict_policy="unknown", strict=False) -> np.ndarray:
+    """s1_s2_classifier.py:133-228, literal per-row loop."""
+
+    def norm(r):
+        if r is None:
+            return None
+        if not isinstance(r, tuple) or len(r) != 2:
+            raise ValueError("range must be a tuple of (min, max)")
+        if r[0] is None and r[1] is None:
+            return None
+        return (None if r[0] is None else float(r[0]), None if r[1] is None else float(r[1]))
+
+    def inside(v, r):
+        if r is None:
+            return True
+        if v is None or np.isnan(v):
+            return False
+        return not ((r[0] is not None and v < r[0]) or (r[1] is not None and v > r[1]))
+
+    s1 = [norm(s1_width_range), norm(s1_area_range), norm(s1_height_range)]
+    s2 = [norm(s2_width_range), norm(s2_area_range), norm(s2_height_range)]
+    s1_on, s2_on = any(r is not None for r in s1), any(r is not None for r in s2)
+    if strict and not s1_on and not s2_on:
+        raise ValueError("No S1/S2 criteria configured; set ranges or disable strict.")
+    rows = []
+    for w in widths:
+        rid = int(w["record_id"]) if "record_id" in w.dtype.names else int(w["event_index"])
+        h = a = np.nan
+        if "record_id" in (features.dtype.names or ()):
+            m = np.flatnonzero(features["record_id"] == rid)
+            if m.size:
+                h, a = float(features["height"][m[0]]), float(features["area"][m[0]])
+        elif 0 <= rid < len(features):
+            h, a = float(features["height"][rid]), float(features["area"][rid])
+        wn, ws = float(w["total_width"]), float(w["total_width_samples"])
+        wv = ws if width_unit == "samples" else wn
+        ok1 = s1_on and inside(wv, s1[0]) and inside(a, s1[1]) and inside(h, s1[2])
+        ok2 = s2_on and inside(wv, s2[0]) and inside(a, s2[1]) and inside(h, s2[2])
+        if ok1 and ok2:
+            label = {"prefer_s1": 1, "prefer_s2": 2}.get(conflict_policy, 0)
+        else:
+            label = 1 if ok1 else (2 if ok2 else 0)
+        rows.append((label, wn, ws, h, a, int(w["timestamp"]), int(w["board"]) if "board" in w.dtype.names else 0,
+                     int(w["channel"]), rid, int(w["peak_position"])))
+    return np.array(rows, dtype=S1_S2_CLASSIFIER_DTYPE) if rows else np.zeros(0, dtype=S1_S2_CLASSIFIER_DTYPE)

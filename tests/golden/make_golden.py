@@ -181,6 +181,71 @@ def peaks_case(name, records, pool, filtered, configs):
     print(f"{name}: {[len(out[f'hit_{k}']) for k in range(len(configs))]} peaks -> {os.path.getsize(path)} B")
 
 
+def st_from_records(records, pool):
+    """Dense ST_WAVEFORM_DTYPE array (processing/dtypes.py:36-64) holding the same waveforms as a uniform-length run."""
+    from waveform_analysis.core.processing.dtypes import create_record_dtype
+
+    L = int(records["event_length"][0])
+    st = np.zeros(len(records), dtype=create_record_dtype(L))
+    for f in ("baseline", "baseline_upstream", "polarity", "timestamp", "record_id", "dt", "event_length", "board",
+              "channel"):
+        st[f] = records[f]
+    st["wave"] = pool.reshape(len(records), L).astype(np.int16)
+    return st
+
+
+def dense_case(name, records, pool, *, filter_cc, width_cfgs, s1s2_cfgs):
+    """Dense branches: FilteredWaveformsPlugin (filtering.py:410-536), BasicFeaturesPlugin st branch
+    (basic_features.py:197-278), HitFinderPlugin dense branch as the producer of `hit`, WaveformWidthPlugin
+    (waveform_width.py:97-374) and S1S2ClassifierPlugin (s1_s2_classifier.py:133-228)."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.plugins.builtin.cpu.filtering import FilteredWaveformsPlugin
+    from waveform_analysis.core.plugins.builtin.cpu.peak_finding import HIT_DTYPE, HitFinderPlugin
+    from waveform_analysis.core.plugins.builtin.cpu.s1_s2_classifier import S1S2ClassifierPlugin
+    from waveform_analysis.core.plugins.builtin.cpu.waveform_width import WaveformWidthPlugin
+
+    st = st_from_records(records, pool)
+    out = {"st_waveforms": st}
+    data = {"st_waveforms": st}
+    out["filtered_waveforms"] = FilteredWaveformsPlugin().compute(Ctx({"max_workers": 1}, data), "run")
+    out["filtered_cc"] = FilteredWaveformsPlugin().compute(Ctx({"max_workers": 1, "channel_config": filter_cc}, data), "run")
+    data["filtered_waveforms"] = out["filtered_waveforms"]
+    out["bf_st"] = BasicFeaturesPlugin().compute(Ctx({}, data), "run")
+    out["bf_filt"] = BasicFeaturesPlugin().compute(Ctx({"use_filtered": True, "height_range": (30, 400),
+                                                        "area_range": (10, 700)}, data), "run")
+    # `hit` rows: the reference's dense detector on the filtered rows, plus hand-made rows for the branches it
+    # never produces (position 0, position past the row, unknown record_id, the plain row maximum)
+    hits = HitFinderPlugin().compute(Ctx({"height": 8.0, "prominence": 0.5, "width": 2}, data), "run")
+    rng = np.random.default_rng(99)
+    L = st["wave"].shape[1]
+    extra = np.zeros(3 * len(st) + 4, dtype=HIT_DTYPE)
+    k = 0
+    for i in range(len(st)):
+        for pos in (int(np.argmax(st["wave"][i])), int(np.argmin(st["wave"][i])), int(rng.integers(0, L))):
+            extra[k] = (pos, 0.0, 0.0, 0.0, 0.0, int(st["dt"][i]), int(st["timestamp"][i]) + pos * int(st["dt"][i]) * 1000,
+                        int(st["board"][i]), int(st["channel"][i]), int(st["record_id"][i]))
+            k += 1
+    extra[k:k + 4] = [(0, 0, 0, 0, 0, 4, 1, 0, 1, int(st["record_id"][0])), (L, 0, 0, 0, 0, 4, 2, 0, 1, int(st["record_id"][1])),
+                      (5, 0, 0, 0, 0, 4, 3, 0, 2, 10**9), (L - 1, 0, 0, 0, 0, 4, 4, 0, 3, int(st["record_id"][2]))]
+    hits = np.concatenate([hits, extra])
+    out["hit"] = hits
+    data["hit"] = hits
+    for k, cfg in enumerate(width_cfgs):
+        out[f"width_{k}"] = WaveformWidthPlugin().compute(Ctx(dict(cfg), data), "run")
+    data["waveform_width"] = out["width_0"]
+    data["basic_features"] = out["bf_st"]
+    for k, cfg in enumerate(s1s2_cfgs):
+        out[f"s1s2_{k}"] = S1S2ClassifierPlugin().compute(Ctx(dict(cfg), data), "run")
+    opts = {"filter_cc": filter_cc, "width": width_cfgs, "s1s2": [{a: list(b) if isinstance(b, tuple) else b for a, b in c.items()} for c in s1s2_cfgs]}
+    out["options_json"] = np.frombuffer(json.dumps(opts).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: hits {len(hits)}, widths {[len(out[f'width_{k}']) for k in range(len(width_cfgs))]}, "
+          f"labels {[np.bincount(out[f's1s2_{k}']['label'], minlength=3).tolist() for k in range(len(s1s2_cfgs))]} "
+          f"-> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -294,6 +359,28 @@ def main():
     fctx = Ctx({"max_workers": 1}, {"records": rec, "wave_pool": pool})
     peaks_case("peaks_ragged", rec, pool, WavePoolFilteredPlugin().compute(fctx, "run"),
                [{"height": 6.0, "width": 1, "prominence": 0.5}, {"use_filtered": False, "height": 6.0, "width": 2}])
+
+    # dense (st_waveforms / filtered_waveforms) branches; half the rows carry positive-going pulses so the
+    # width plugin (which only keeps peaks above the row baseline) sees real pulses
+    rec, pool = synth.make_run(40, "v1725", cfg=17)
+    rpos, ppos = flip_positive(rec[::2], pool.reshape(len(rec), -1)[::2].reshape(-1))
+    rmix = np.concatenate([rpos, rec[1::2]])
+    pmix = np.concatenate([ppos, pool.reshape(len(rec), -1)[1::2].reshape(-1)])
+    rmix["wave_offset"] = np.arange(len(rmix)) * 800
+    rmix["record_id"] = np.arange(len(rmix))
+    dense_case("dense_v1725", rmix, pmix,
+               filter_cc={"0:3": {"sg_window_size": 7, "sg_poly_order": 3},
+                          "0:5": {"filter_type": "BW", "lowcut": 0.01, "highcut": 0.2, "fs": 0.5},
+                          "0:9": {"sg_window_size": 20, "sg_poly_order": 4}},
+               width_cfgs=[{}, {"use_filtered": True}, {"interpolation": False, "sampling_rate": 0.3},
+                           {"use_filtered": True, "sampling_rate": 0.3, "rise_low": 0.2, "rise_high": 0.8,
+                            "fall_high": 0.7, "fall_low": 0.3},
+                           {"use_filtered": True, "interpolation": False, "sampling_rate": 1.0}],
+               s1s2_cfgs=[{}, {"s1_width_range": (None, 60.0), "s2_width_range": (60.0, None)},
+                          {"width_unit": "samples", "s1_width_range": (0.0, 40.0), "s1_area_range": (None, 5000.0),
+                           "s2_width_range": (20.0, None), "s2_height_range": (50.0, None),
+                           "conflict_policy": "prefer_s2"},
+                          {"s1_height_range": (10.0, 1e9), "s2_area_range": (-1e9, 1e9), "conflict_policy": "prefer_s1"}])
 
     # event grouping of threshold hits from a 16-channel run and from a 256-channel run
     for preset, cfg, nrec in (("v1725", 8, 400), ("vx2730", 9, 600)):

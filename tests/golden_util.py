@@ -13,7 +13,7 @@ from waveformanalysis_amd.channel_config import per_record_option, scatter_per_r
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names(prefix_exclude=("grouping_", "peaks_")):
+def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_")):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
     return [n for n in names if not n.startswith(tuple(prefix_exclude))]
 
@@ -23,13 +23,29 @@ def grouping_case_names():
 
 
 def peaks_case_names():
-    return [n for n in case_names(prefix_exclude=()) if n.startswith("peaks_")]
+    return [n for n in case_names(prefix_exclude=()) if n.startswith(("peaks_", "dense_"))]
 
 
 def load_peaks(name):
     z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
     d = {k: z[k] for k in z.files}
     d["configs"] = json.loads(bytes(d.pop("options_json")).decode())
+    return d
+
+
+def dense_case_names():
+    return sorted(os.path.splitext(f)[0] for f in os.listdir(GOLDEN) if f.startswith("dense_") and f.endswith(".npz"))
+
+
+def load_dense(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    opt = json.loads(bytes(d.pop("options_json")).decode())
+    for cfg in opt["s1s2"]:
+        for k, v in cfg.items():
+            if isinstance(v, list):
+                cfg[k] = tuple(v)
+    d["options"] = opt
     return d
 
 

@@ -89,9 +89,16 @@ def test_channel_config_layers():
 
 def test_plugin_contract_attributes():
     for p in hip_default():
-        assert p.provides and p.save_when == "always"
+        assert p.provides and p.save_when == ("target" if p.provides == "filtered_waveforms" else "always")
         assert p.output_dtype is not None or p.provides == "hit_grouped"  # DataFrame product
-        assert "wave_source" in p.options or p.provides in ("wave_pool_filtered", "hit_grouped")
+        assert "wave_source" in p.options or p.provides in ("wave_pool_filtered", "hit_grouped", "filtered_waveforms",
+                                                             "waveform_width", "s1_s2")
+    bf = [p for p in hip_default() if p.provides == "basic_features"][0]
+    assert bf.resolve_depends_on(SimpleContext({})) == ["st_waveforms"]  # reference default: wave_source="auto"
+    assert bf.resolve_depends_on(SimpleContext({"use_filtered": True})) == ["filtered_waveforms"]
+    assert bf.resolve_depends_on(SimpleContext({"wave_source": "records", "use_filtered": True})) == ["records", "wave_pool_filtered"]
+    ww = [p for p in hip_default() if p.provides == "waveform_width"][0]
+    assert ww.resolve_depends_on(SimpleContext({"use_filtered": True})) == ["hit", "filtered_waveforms"]
     hit = [p for p in hip_default() if p.provides == "hit_threshold"][0]
     ctx = SimpleContext({"use_filtered": True})
     assert hit.resolve_depends_on(ctx) == ["records", "wave_pool_filtered"]

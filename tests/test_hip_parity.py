@@ -150,7 +150,7 @@ def test_plugins_drop_in_chain():
     case = G.load_case("v1725_channel_cfg")
     opt = case["options"]
     ctx = SimpleContext(
-        {"hit_threshold": {**opt["hit"], "use_filtered": True}, "basic_features": opt["bf"]},
+        {"hit_threshold": {**opt["hit"], "use_filtered": True}, "basic_features": {**opt["bf"], "wave_source": "records"}},
         {"records": case["records"], "wave_pool": case["wave_pool"]},
         plugins=[HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
                  HipWaveformWidthIntegralPlugin()],
@@ -316,7 +316,7 @@ def test_full_size_properties():
 def test_butterworth_sosfiltfilt_bit_exact(sess):
     """Butterworth branch of wave_pool_filtered: the lane-per-record kernel runs scipy's sosfiltfilt
     recursion literally -> bit-exact float32 against the reference fixture and the oracle."""
-    from waveformanalysis_amd.plugins.wave_pool_filtered import design_bw
+    from waveformanalysis_amd.filter_engine import design_bw
 
     case = G.load_case("v1725_bw")
     fp = G.filter_params(case)

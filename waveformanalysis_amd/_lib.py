@@ -21,7 +21,7 @@ WFA_E_RCCL = -5
 WFA_E_LIMIT = -6
 
 SRC_RAW, SRC_F32, SRC_SG_FUSED = 0, 1, 2
-POL_UNKNOWN, POL_NEGATIVE, POL_POSITIVE = 0, 1, 2
+POL_UNKNOWN, POL_NEGATIVE, POL_POSITIVE, POL_POSITIVE_WAVE = 0, 1, 2, 3
 ABI_VERSION = 1
 
 _p = C.c_void_p
@@ -40,6 +40,8 @@ SIGNATURES = {
     "wfa_upload_records_soa": (_int, [_p, _i64] + [_p] * 10),
     "wfa_set_sg_plan": (_int, [_p, _int, _int, _p, _p, _int, _p, _i32, _i32, _i64, _i64]),
     "wfa_baseline_mean": (_int, [_p, _i32, _i32, _int, _p]),
+    "wfa_filter_keep_output": (_int, [_p, _int]),
+    "wfa_download_pool_f32": (_int, [_p, _p, _i64]),
     "wfa_savgol": (_int, [_p, _p]),
     "wfa_sosfiltfilt": (_int, [_p, _int, _p, _p, _i32, _p]),
     "wfa_threshold_hits_count": (_int, [_p, _int, _i32, _i32, _i32, C.POINTER(_i64)]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     "wfa_fused_baseline_filter_hits": (_int, [_p, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
     "wfa_find_peaks_count": (_int, [_p, _int, _int, _f64, _int, _f64, _i32, _f64, _f64, _int, _i32, C.POINTER(_i64)]),
     "wfa_find_peaks_fill": (_int, [_p, _p, _i64]),
+    "wfa_waveform_width": (_int, [_p, _int, _i64, _p, _p, _i64, _i32, _f64, _f64, _f64, _f64, _f64, _int, _p, _p]),
     "wfa_basic_features": (_int, [_p, _int, _i64, _i64, _int, _i64, _i64, _int, _p, _p]),
     "wfa_width_integral": (_int, [_p, _int, _f64, _f64, _f64, _p]),
     "wfa_profile_enable": (_int, [_p, _int]),

@@ -344,7 +344,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
                       &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
-                        &c->peak_cand_state, &c->sg.mfma, &c->sg.tab,
+                        &c->peak_cand_state, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.mfma, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
@@ -370,6 +370,7 @@ int wfa_upload_pool_u16(wfa_ctx* c, const uint16_t* pool, int64_t n) {
     c->pool_n = n;
     c->have_u16 = true;
     c->have_f32 = false;  // a filtered pool belongs to the previous wave_pool
+    c->filter_keep = false;
     c->have_records = false;
     return WFA_OK;
 }
@@ -409,7 +410,7 @@ int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int3
         if (len[r] > WFA_MAX_RECORD_SAMPLES)
             return fail(WFA_E_LIMIT, "record %lld has %d samples; this build supports at most %d",
                         (long long)r, len[r], WFA_MAX_RECORD_SAMPLES);
-        if (pol[r] < WFA_POL_UNKNOWN || pol[r] > WFA_POL_POSITIVE)
+        if (pol[r] < WFA_POL_UNKNOWN || pol[r] > WFA_POL_POSITIVE_WAVE)
             return fail(WFA_E_INVALID, "bad polarity code %d at record %lld", (int)pol[r], (long long)r);
         if (len[r] > max_len) max_len = len[r];
     }
@@ -542,13 +543,34 @@ int wfa_baseline_mean(wfa_ctx* c, int32_t start, int32_t end, int update_records
     return WFA_OK;
 }
 
+int wfa_filter_keep_output(wfa_ctx* c, int keep) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (keep && (!c->have_f32 || c->pool_f32.cap < (size_t)c->pool_n * sizeof(float)))
+        return fail(WFA_E_STATE, "keep requested but no filtered output exists yet");
+    c->filter_keep = keep != 0;
+    return WFA_OK;
+}
+
+int wfa_download_pool_f32(wfa_ctx* c, float* out, int64_t n) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (!c->have_f32) return fail(WFA_E_STATE, "no float32 pool is resident");
+    if (n != c->pool_n) return fail(WFA_E_INVALID, "caller expects %lld samples, the pool has %lld", (long long)n, (long long)c->pool_n);
+    if (n == 0) return WFA_OK;
+    if (!out) return fail(WFA_E_INVALID, "out is null");
+    WFA_HIP_CHECK(hipMemcpyAsync(out, c->pool_f32.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
 int wfa_savgol(wfa_ctx* c, float* out) {
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = need_source(c, WFA_SRC_SG_FUSED))) return rc;
     if ((rc = c->pool_f32.ensure((size_t)c->pool_n * sizeof(float)))) return rc;
     // gaps between records stay 0.0 (records.py:382)
-    WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
+    if (!c->filter_keep) WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
     if (c->R > 0) {
         PoolView pv = pool_view(c);
         const SgParams sp0 = sg_params(c);
@@ -581,7 +603,7 @@ int wfa_sosfiltfilt(wfa_ctx* c, int n_sections, const double* sos, const double*
     if (n_sections < 1 || n_sections > 8) return fail(WFA_E_INVALID, "n_sections must be in [1, 8], got %d", n_sections);
     if (!sos || !zi || padlen < 0) return fail(WFA_E_INVALID, "bad sosfiltfilt arguments");
     if ((rc = c->pool_f32.ensure((size_t)c->pool_n * sizeof(float)))) return rc;
-    WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
+    if (!c->filter_keep) WFA_HIP_CHECK(hipMemsetAsync(c->pool_f32.ptr, 0, (size_t)c->pool_n * sizeof(float), c->stream));
     if (c->R > 0) {
         // forward-pass scratch: [max_len + 2 padlen][batch] float64, batches bounded to ~2 GiB
         const int64_t n_ext = (int64_t)c->max_len + 2 * (int64_t)padlen;
@@ -763,6 +785,43 @@ int wfa_basic_features(wfa_ctx* c, int source, int64_t h0, int64_t h1, int h_has
         if ((rc = t.end("k_basic_features"))) return rc;
     }
     WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 36, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_waveform_width(wfa_ctx* c, int source, int64_t n_hits, const int64_t* position, const int64_t* row_index,
+                       int64_t n_rows, int32_t row_length, double rise_low, double rise_high, double fall_high,
+                       double fall_low, double sampling_rate, int interpolation, void* out_rows, uint8_t* valid) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32)
+        return fail(WFA_E_INVALID, "waveform_width reads dense rows: source must be WFA_SRC_RAW or WFA_SRC_F32");
+    if (source == WFA_SRC_RAW ? !c->have_u16 : !c->have_f32) return fail(WFA_E_STATE, "no wave matrix uploaded for this source");
+    if (n_hits < 0 || n_rows < 0 || row_length < 0) return fail(WFA_E_INVALID, "negative size");
+    if (n_rows * (int64_t)row_length > c->pool_n)
+        return fail(WFA_E_INVALID, "wave matrix %lld x %d exceeds the resident pool (%lld samples)", (long long)n_rows,
+                    row_length, (long long)c->pool_n);
+    if (n_hits == 0) return WFA_OK;
+    if (!position || !row_index || !out_rows || !valid) return fail(WFA_E_INVALID, "null argument");
+    if (!(sampling_rate == sampling_rate) || sampling_rate == 0.0) return fail(WFA_E_INVALID, "float division by zero");
+    // scratch: positions, row indices, rows, valid bytes
+    const size_t b_idx = (size_t)n_hits * sizeof(int64_t);
+    if ((rc = c->wh_pos.ensure(b_idx))) return rc;
+    if ((rc = c->wh_row.ensure(b_idx))) return rc;
+    if ((rc = c->out_rows.ensure((size_t)n_hits * 56))) return rc;
+    if ((rc = c->wh_valid.ensure((size_t)n_hits))) return rc;
+    WFA_HIP_CHECK(hipMemcpyAsync(c->wh_pos.ptr, position, b_idx, hipMemcpyHostToDevice, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(c->wh_row.ptr, row_index, b_idx, hipMemcpyHostToDevice, c->stream));
+    {
+        LaunchTimer t(c);
+        WFA_HIP_CHECK(launch_waveform_width(c->stream, source, pool_view(c), n_hits, c->wh_pos.as<int64_t>(),
+                                            c->wh_row.as<int64_t>(), n_rows, row_length, rise_low, rise_high, fall_high,
+                                            fall_low, sampling_rate, interpolation, c->out_rows.as<uint8_t>(),
+                                            c->wh_valid.as<uint8_t>()));
+        if ((rc = t.end("k_waveform_width"))) return rc;
+    }
+    WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)n_hits * 56, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(valid, c->wh_valid.ptr, (size_t)n_hits, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return WFA_OK;
 }

@@ -87,6 +87,7 @@ struct wfa_ctx {
 
     wfa::SgPlanDev sg;
     bool have_sg = false;
+    bool filter_keep = false;  // wfa_filter_keep_output
 
     // hit scratch
     wfa::DevBuf hit_tmp;        // 60 B rows in chunk order
@@ -105,6 +106,7 @@ struct wfa_ctx {
     wfa::DevBuf peak_out;  // HIT_DTYPE rows of the last find_peaks pass
     int64_t n_peaks = -1;
     wfa::DevBuf peak_cand_n, peak_cand_pos, peak_cand_val, peak_cand_state;  // distance > 2: candidate lists
+    wfa::DevBuf wh_pos, wh_row, wh_valid;  // per-hit inputs of k_waveform_width
     wfa::DevBuf bw_scratch;  // float64 forward pass of sosfiltfilt, [sample][record-in-batch]
 
     // profiling

@@ -2064,6 +2064,7 @@ __global__ __launch_bounds__(kFeatBlock) void k_basic_features(PoolView pool, Re
     }
     const int pol = rec.pol[r];
     const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
+    const bool wpos = pol == WFA_POL_POSITIVE_WAVE;  // st_waveforms branch, polarity "positive" (basic_features.py:245-262)
     const float b32 = (float)baseline;
     int p0, p1, c0, c1;
     py_slice(fp.h0, fp.h1, fp.h_has_end, L, p0, p1);
@@ -2091,7 +2092,7 @@ __global__ __launch_bounds__(kFeatBlock) void k_basic_features(PoolView pool, Re
                         term = val;                                                                  \
                     } else {                                                                         \
                         val = wd[JJ];                                                                \
-                        term = baseline - wd[JJ]; /* effective polarity "negative" */                \
+                        term = wpos ? wd[JJ] - baseline : baseline - wd[JJ]; /* "negative" unless dense-positive */ \
                     }                                                                                \
                     if (i >= p0 && i < p1) { vmin = val < vmin ? val : vmin; vmax = val > vmax ? val : vmax; } \
                     if (i >= c0 && i < c1) pw.feed<JJ>(term);                                        \
@@ -2106,7 +2107,7 @@ __global__ __launch_bounds__(kFeatBlock) void k_basic_features(PoolView pool, Re
     }
     float height = 0.f, amp = 0.f, area_f = 0.f, mad_f = 0.f;
     if (p1 > p0) {
-        height = known ? (float)vmax : (float)(baseline - vmin);
+        height = known ? (float)vmax : (wpos ? (float)(vmax - baseline) : (float)(baseline - vmin));
         amp = (float)(vmax - vmin);
     }
     if (c1 > c0) area_f = (float)pw.result();
@@ -2199,6 +2200,161 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
     put_i64(row, 8, rec.ts[r]);
     row[10] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
     put_i64(row, 11, r);
+}
+
+// =============================================================================================
+// K10: rise / fall / total width per hit on dense rows  (waveform_width.py:205-374)
+// =============================================================================================
+// One lane per hit.  T = double for int16 rows (numpy promotes int16 - float64 mean to float64), float for
+// float32 rows (mean, subtraction, thresholds, interpolation all stay float32 under numpy 2 promotion).
+// numpy float32 pairwise_sum of x[0..n), n <= 128 (np.mean / np.sum of a short float32 slice)
+__device__ inline float np_pairwise_leaf_f32(const float* x, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res += x[i];
+        return res;
+    }
+    float r0 = x[0], r1 = x[1], r2 = x[2], r3 = x[3], r4 = x[4], r5 = x[5], r6 = x[6], r7 = x[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += x[i]; r1 += x[i + 1]; r2 += x[i + 2]; r3 += x[i + 3];
+        r4 += x[i + 4]; r5 += x[i + 5]; r6 += x[i + 6]; r7 += x[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += x[i];
+    return res;
+}
+
+struct WidthHitParams {
+    double rise_low, rise_high, fall_high, fall_low, sampling_rate;
+    int interpolation;
+    int32_t L;
+    int64_t n_rows;
+};
+
+// value that is either a python float / np.float64 (is32 = false) or an np.float32 (is32 = true)
+struct PyNum {
+    double v;
+    bool is32;
+    bool none;
+};
+
+template <typename T, typename LoadF>
+__device__ PyNum find_crossing(const LoadF& at, int lo, int hi, T thr, bool rising, bool interp) {
+    PyNum out{0.0, false, true};
+    // first index (relative to lo) whose value is >= thr (rising) / <= thr (falling)
+    int idx = -1;
+    for (int i = lo; i < hi; ++i) {
+        const T y = at(i);
+        if (rising ? (y >= thr) : (y <= thr)) { idx = i - lo; break; }
+    }
+    if (idx < 0) return out;
+    out.none = false;
+    out.v = (double)idx;  // float(idx): python float
+    if (!interp || idx == 0) return out;
+    const T y0 = at(lo + idx - 1), y1 = at(lo + idx);
+    const T d = y1 - y0;
+    const T ad = d < (T)0 ? -d : d;
+    if (ad < (T)1e-10) return out;  // python float 1e-10 is weak: compared in T
+    const T fraction = (thr - y0) / d;
+    const T pos = (T)(idx - 1) + fraction;  // float(idx - 1) + fraction in T
+    out.v = (double)pos;
+    out.is32 = sizeof(T) == 4;
+    return out;
+}
+
+__device__ __forceinline__ PyNum py_sub(const PyNum& a, const PyNum& b) {
+    PyNum r{0.0, a.is32 || b.is32, false};
+    r.v = r.is32 ? (double)((float)a.v - (float)b.v) : a.v - b.v;
+    return r;
+}
+
+__device__ __forceinline__ PyNum py_div(const PyNum& a, double python_float) {
+    PyNum r{0.0, a.is32, false};
+    r.v = a.is32 ? (double)((float)a.v / (float)python_float) : a.v / python_float;
+    return r;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(128) void k_waveform_width(PoolView pool, int64_t n_hits,
+                                                        const int64_t* __restrict__ position,
+                                                        const int64_t* __restrict__ row_index, WidthHitParams wp,
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ valid) {
+    using T = typename std::conditional<SRC == WFA_SRC_RAW, double, float>::type;
+    const int64_t h = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (h >= n_hits) return;
+    uint32_t* row = reinterpret_cast<uint32_t*>(out + h * 56);
+#pragma unroll
+    for (int k = 0; k < 14; ++k) row[k] = 0u;
+    valid[h] = 0;
+    const int64_t ri = row_index[h];
+    const int64_t pos64 = position[h];
+    const int L = wp.L;
+    if (ri < 0 || ri >= wp.n_rows || L <= 0) return;
+    if (pos64 >= L || pos64 < 0) return;  // waveform_width.py:252
+    const int peak = (int)pos64;
+    const uint16_t* xu = pool.u16 ? pool.u16 + ri * L : nullptr;
+    const float* xf = pool.f32 ? pool.f32 + ri * L : nullptr;
+
+    // baseline = np.mean(waveform[:50])
+    const int nb = L < 50 ? L : 50;
+    T baseline;
+    if (SRC == WFA_SRC_RAW) {
+        double sum = 0.0;  // integers: exact in float64 whatever the order
+        for (int i = 0; i < nb; ++i) sum += (double)xu[i];
+        baseline = (T)(sum / (double)nb);
+    } else {
+        const float sum = np_pairwise_leaf_f32(xf, nb);
+        baseline = (T)(sum / (float)nb);
+    }
+    auto at = [&](int i) -> T {
+        if (SRC == WFA_SRC_RAW) return (T)((double)xu[i] - (double)baseline);
+        return (T)(xf[i] - (float)baseline);
+    };
+    const T peak_value = at(peak);
+    if (!(peak_value > (T)0)) return;  // waveform_width.py:258 (NaN also compares false there -> kept; NaN is not produced)
+    const bool interp = wp.interpolation != 0;
+    // python float options are weak: thresholds take the dtype of peak_value
+    const T thr_rl = peak_value * (T)wp.rise_low, thr_rh = peak_value * (T)wp.rise_high;
+    const T thr_fh = peak_value * (T)wp.fall_high, thr_fl = peak_value * (T)wp.fall_low;
+    const PyNum rise_lo = find_crossing<T>(at, 0, peak, thr_rl, true, interp);
+    const PyNum rise_hi = find_crossing<T>(at, 0, peak, thr_rh, true, interp);
+    PyNum fall_hi = find_crossing<T>(at, peak, L, thr_fh, false, interp);
+    PyNum fall_lo = find_crossing<T>(at, peak, L, thr_fl, false, interp);
+
+    PyNum rise_s{0.0, false, false}, rise_t{0.0, false, false};
+    if (!rise_lo.none && !rise_hi.none) {
+        rise_s = py_sub(rise_hi, rise_lo);
+        rise_t = py_div(rise_s, wp.sampling_rate);
+    }
+    PyNum fall_s{0.0, false, false}, fall_t{0.0, false, false};
+    if (!fall_hi.none && !fall_lo.none) {
+        // += np.int64 peak_position promotes to float64 whatever the left side was
+        fall_hi.v = fall_hi.v + (double)peak; fall_hi.is32 = false;
+        fall_lo.v = fall_lo.v + (double)peak; fall_lo.is32 = false;
+        fall_s = py_sub(fall_lo, fall_hi);
+        fall_t = py_div(fall_s, wp.sampling_rate);
+    }
+    PyNum tot_s{0.0, false, false}, tot_t{0.0, false, false};
+    if (!rise_lo.none && !fall_lo.none) {
+        // fall_low_pos is float64 only if the fall branch above ran (it needs fall_high_pos too)
+        if (!fall_lo.is32 && (!fall_hi.none)) {
+            tot_s.v = fall_lo.v - rise_lo.v;  // np.float64 - (np.float32 | python float) -> float64
+            tot_s.is32 = false;
+        } else {
+            tot_s = py_sub(fall_lo, rise_lo);
+        }
+        tot_t = py_div(tot_s, wp.sampling_rate);
+    }
+    put_f32(row, 0, (float)rise_t.v);
+    put_f32(row, 1, (float)fall_t.v);
+    put_f32(row, 2, (float)tot_t.v);
+    put_f32(row, 3, (float)rise_s.v);
+    put_f32(row, 4, (float)fall_s.v);
+    put_f32(row, 5, (float)tot_s.v);
+    put_i64(row, 6, pos64);
+    put_f32(row, 8, (float)peak_value);
+    valid[h] = 1;
 }
 
 // =============================================================================================
@@ -2708,6 +2864,22 @@ hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecVie
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_sosfiltfilt, dim3(grid), dim3(kBlock), 0, st, pool, rec, sp, r_begin, r_end, scratch,
                        batch_stride, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_waveform_width(hipStream_t st, int source, const PoolView& pool, int64_t n_hits,
+                                 const int64_t* position, const int64_t* row_index, int64_t n_rows, int32_t L,
+                                 double rise_low, double rise_high, double fall_high, double fall_low,
+                                 double sampling_rate, int interpolation, uint8_t* out, uint8_t* valid) {
+    if (n_hits == 0) return hipSuccess;
+    WidthHitParams wp{rise_low, rise_high, fall_high, fall_low, sampling_rate, interpolation, L, n_rows};
+    const unsigned grid = (unsigned)((n_hits + 127) / 128);
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_waveform_width<WFA_SRC_RAW>), dim3(grid), dim3(128), 0, st, pool, n_hits, position, row_index, wp, out, valid);
+    else if (source == WFA_SRC_F32)
+        hipLaunchKernelGGL((k_waveform_width<WFA_SRC_F32>), dim3(grid), dim3(128), 0, st, pool, n_hits, position, row_index, wp, out, valid);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

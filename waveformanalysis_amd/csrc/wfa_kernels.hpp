@@ -125,6 +125,10 @@ hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t*
 hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecView& rec, int n_sections,
                               const double* sos, const double* zi, int edge, int64_t r_begin, int64_t r_end,
                               double* scratch, int64_t batch_stride, float* out);
+hipError_t launch_waveform_width(hipStream_t st, int source, const PoolView& pool, int64_t n_hits,
+                                 const int64_t* position, const int64_t* row_index, int64_t n_rows, int32_t L,
+                                 double rise_low, double rise_high, double fall_high, double fall_low,
+                                 double sampling_rate, int interpolation, uint8_t* out, uint8_t* valid);
 // mode 0/1: count/fill final rows from the stream (distance <= 2); 2/3: count/fill the candidate list
 hipError_t launch_find_peaks(hipStream_t st, int source, int mode, const PoolView& pool, const RecView& rec,
                              const PeakParams& pp, int32_t* counts, const int64_t* out_start, uint8_t* out,

@@ -17,6 +17,7 @@ from . import _lib
 from .dtypes import (
     BASIC_FEATURES_DTYPE,
     HIT_DTYPE,
+    WAVEFORM_WIDTH_DTYPE,
     THRESHOLD_HIT_DTYPE,
     WAVEFORM_WIDTH_INTEGRAL_DTYPE,
 )
@@ -109,7 +110,9 @@ class DeviceSession:
             raise ValueError(f"wave_pool_filtered has {arr.size} samples, wave_pool has {self.n_samples}")
         _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
 
-    def upload_records(self, records: np.ndarray, thresholds: np.ndarray | float = 10.0) -> None:
+    def upload_records(self, records: np.ndarray, thresholds: np.ndarray | float = 10.0,
+                       polarity: np.ndarray | None = None) -> None:
+        """records -> device SoA.  `polarity`: optional int8 WFA_POL_* codes overriding records["polarity"]."""
         if records.dtype.names is None:
             raise ValueError("records must be a structured array")
         missing = [n for n in REQUIRED_RECORD_FIELDS if n not in records.dtype.names]
@@ -125,7 +128,7 @@ class DeviceSession:
             _col(records, "wave_offset", np.int64),
             _col(records, "event_length", np.int32),
             _col(records, "baseline", np.float64),
-            polarity_codes(records),
+            polarity_codes(records) if polarity is None else np.ascontiguousarray(polarity, dtype=np.int8),
             thr,
             _col(records, "timestamp", np.int64),
             _col(records, "dt", np.int32, default=1),
@@ -152,6 +155,16 @@ class DeviceSession:
     def baseline_mean(self, start: int, end: int, update_records: bool = False) -> np.ndarray:
         out = np.empty(self.n_records, dtype=np.float64)
         _lib.check(self._lib.wfa_baseline_mean(self._h, int(start), int(end), int(update_records), _ptr(out)))
+        return out
+
+    def filter_keep_output(self, keep: bool) -> None:
+        """keep=True: the next savgol/sosfiltfilt calls write only their records' slices into the output."""
+        _lib.check(self._lib.wfa_filter_keep_output(self._h, int(bool(keep))))
+
+    def download_filtered(self) -> np.ndarray:
+        """The resident float32 pool (after one or more filter calls)."""
+        out = np.empty(self.n_samples, dtype=np.float32)
+        _lib.check(self._lib.wfa_download_pool_f32(self._h, _ptr(out), out.size))
         return out
 
     def savgol(self, download: bool = True) -> np.ndarray | None:
@@ -205,6 +218,25 @@ class DeviceSession:
         out = np.empty(int(n.value), dtype=HIT_DTYPE)
         _lib.check(self._lib.wfa_find_peaks_fill(self._h, _ptr(out), int(n.value)))
         return out
+
+    def waveform_width(self, source: int, position: np.ndarray, row_index: np.ndarray, n_rows: int, row_length: int,
+                       rise_low: float = 0.1, rise_high: float = 0.9, fall_high: float = 0.9, fall_low: float = 0.1,
+                       sampling_rate: float = 0.5, interpolation: bool = True) -> tuple[np.ndarray, np.ndarray]:
+        """Rise/fall/total width per hit on the resident dense wave matrix (WaveformWidthPlugin).
+
+        Returns (rows, valid): WAVEFORM_WIDTH_DTYPE rows for every hit (id fields zero) and the bool mask of
+        hits the reference keeps."""
+        pos = np.ascontiguousarray(position, dtype=np.int64)
+        row = np.ascontiguousarray(row_index, dtype=np.int64)
+        if pos.shape != row.shape or pos.ndim != 1:
+            raise ValueError("position and row_index must be 1-D arrays of the same length")
+        out = np.zeros(len(pos), dtype=WAVEFORM_WIDTH_DTYPE)
+        valid = np.zeros(len(pos), dtype=np.uint8)
+        _lib.check(self._lib.wfa_waveform_width(
+            self._h, int(source), len(pos), _ptr(pos), _ptr(row), int(n_rows), int(row_length), float(rise_low),
+            float(rise_high), float(fall_high), float(fall_low), float(sampling_rate), int(bool(interpolation)),
+            _ptr(out), _ptr(valid)))
+        return out, valid.astype(bool)
 
     def basic_features(self, source: int = _lib.SRC_RAW, height_range=(40, 90), area_range=(0, None),
                        fixed_baseline: np.ndarray | None = None) -> np.ndarray:

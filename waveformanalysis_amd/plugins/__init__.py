@@ -6,17 +6,22 @@ with ``ctx.register(p, allow_override=True)`` to replace the CPU plugins of the 
 """
 
 from .basic_features import HipBasicFeaturesPlugin
+from .filtered_waveforms import HipFilteredWaveformsPlugin
 from .hit_finder import HipHitFinderPlugin
 from .hit_grouped import HipHitGroupedPlugin
+from .s1_s2 import HipS1S2ClassifierPlugin
 from .threshold_hit import HipThresholdHitPlugin
 from .wave_pool_filtered import HipWavePoolFilteredPlugin
+from .waveform_width import HipWaveformWidthPlugin
 from .width_integral import HipWaveformWidthIntegralPlugin
 
 
 def hip_default():
     return [HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
-            HipWaveformWidthIntegralPlugin(), HipHitGroupedPlugin(), HipHitFinderPlugin()]
+            HipWaveformWidthIntegralPlugin(), HipHitGroupedPlugin(), HipHitFinderPlugin(),
+            HipFilteredWaveformsPlugin(), HipWaveformWidthPlugin(), HipS1S2ClassifierPlugin()]
 
 
 __all__ = ["HipWavePoolFilteredPlugin", "HipThresholdHitPlugin", "HipBasicFeaturesPlugin",
-           "HipWaveformWidthIntegralPlugin", "HipHitGroupedPlugin", "HipHitFinderPlugin", "hip_default"]
+           "HipWaveformWidthIntegralPlugin", "HipHitGroupedPlugin", "HipHitFinderPlugin", "HipFilteredWaveformsPlugin",
+           "HipWaveformWidthPlugin", "HipS1S2ClassifierPlugin", "hip_default"]

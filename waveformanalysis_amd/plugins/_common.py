@@ -51,6 +51,43 @@ def records_dependencies(context: Any, plugin: Any) -> tuple[list[str], str]:
     return ["records", "wave_pool"], "wave_pool"
 
 
+WAVE_SOURCE_ST = "st_waveforms"
+WAVE_SOURCE_FILTERED = "filtered_waveforms"
+
+
+def resolve_wave_input(context: Any, plugin: Any) -> tuple[str, list[str], str]:
+    """(kind, depends_on, data_name) for plugins that implement the records AND the dense branches
+    (cpu/_wave_source.py:74-172): kind is "records" or "dense"; data_name is the pool name for records,
+    the structured-array name for dense.  An explicit wave_source wins; "auto" picks the dense array by
+    use_filtered."""
+    source = normalize_wave_source(context.get_config(plugin, "wave_source"))
+    use_filtered = bool(context.get_config(plugin, "use_filtered")) if "use_filtered" in plugin.options else False
+    if source == WAVE_SOURCE_RECORDS:
+        pool = "wave_pool_filtered" if use_filtered else "wave_pool"
+        return "records", [WAVE_SOURCE_RECORDS, pool], pool
+    if source in (WAVE_SOURCE_ST, WAVE_SOURCE_FILTERED):
+        if use_filtered:
+            warnings.warn(f"Ignoring {plugin.provides}.use_filtered because wave_source={source} explicitly "
+                          "selects data source.", stacklevel=3)
+        return "dense", [source], source
+    name = WAVE_SOURCE_FILTERED if use_filtered else WAVE_SOURCE_ST
+    return "dense", [name], name
+
+
+def load_dense_input(context: Any, plugin: Any, run_id: str, data_name: str) -> np.ndarray:
+    """cpu/_wave_source.py:215-227."""
+    plugins = getattr(context, "_plugins", None)
+    if isinstance(plugins, dict) and plugins and data_name not in plugins and data_name not in getattr(context, "_data", {}):
+        message = f"{plugin.provides} requires '{data_name}' but it is not registered."
+        if data_name == WAVE_SOURCE_FILTERED:
+            message += f" Register FilteredWaveformsPlugin to provide '{data_name}'."
+        raise KeyError(message)
+    data = context.get_data(run_id, data_name)
+    if not isinstance(data, np.ndarray):
+        raise ValueError(f"{plugin.provides} expects {data_name} as a single structured array")
+    return data
+
+
 def load_records_input(context: Any, plugin: Any, run_id: str, pool_name: str):
     plugins = getattr(context, "_plugins", None)
     if isinstance(plugins, dict) and plugins:

@@ -8,7 +8,7 @@ from typing import Any
 import numpy as np
 
 from ..plugin_api import Option, Plugin
-from ..sg_plan import normalize_window
+from ..filter_engine import design_bw, plan_filter_groups, run_filter_groups  # noqa: F401 (design_bw re-exported)
 from . import _common as K
 
 
@@ -52,18 +52,11 @@ class HipWavePoolFilteredPlugin(Plugin):
         if batch_size < 0:
             raise ValueError(f"batch_size ({batch_size}) 必须大于等于 0")
 
-        filter_type = str(context.get_config(self, "filter_type"))
-        if filter_type not in ("BW", "SG"):
-            raise ValueError(f"不支持的滤波器类型: {filter_type}. 请使用 'BW' 或 'SG'.")
-        if context.get_config(self, "channel_config"):
-            raise NotImplementedError("HIP backend: per-channel filter overrides are not implemented yet")
-        bw = None
-        if filter_type == "BW":
-            bw = design_bw(context.get_config(self, "lowcut"), context.get_config(self, "highcut"),
-                           context.get_config(self, "fs"), context.get_config(self, "filter_order"))
-        else:
-            window, order = normalize_window(context.get_config(self, "sg_window_size"),
-                                             context.get_config(self, "sg_poly_order"))
+        n = len(records)
+        names = records.dtype.names
+        boards = records["board"] if "board" in names else np.zeros(n, dtype=np.int16)
+        channels = records["channel"] if "channel" in names else np.zeros(n, dtype=np.int16)
+        groups = plan_filter_groups(context, self, run_id, boards, channels)
 
         off = records["wave_offset"].astype(np.int64)
         length = records["event_length"].astype(np.int64)
@@ -73,37 +66,9 @@ class HipWavePoolFilteredPlugin(Plugin):
             raise ValueError("wave_pool_filtered found out-of-bounds wave slice "
                              f"(offset={int(off[i])}, length={int(length[i])}, wave_pool_size={len(wave_pool)})")
         sess = K.resident_session(context, np.asarray(wave_pool))
-        sess.upload_records(_view_records(records))
-        if bw is not None:
-            out = sess.sosfiltfilt(*bw, download=True)
-        else:
-            sess.set_sg_plan(window, order)
-            out = sess.savgol(download=True)
+        out = run_filter_groups(sess, _view_records(records), groups)
         K.invalidate_residency()  # the resident float32 pool now belongs to this output
         return out
-
-
-def design_bw(lowcut, highcut, fs, order):
-    """Filter design on the host exactly as the reference validates and designs it
-    (filtering.py:84-101) + scipy's steady-state initial conditions and the pad length of
-    filtering.py:198-203.  Returns (sos, zi, padlen)."""
-    from scipy.signal import butter, sosfilt_zi
-
-    lowcut, highcut, fs, order = float(lowcut), float(highcut), float(fs), int(order)
-    if fs <= 0:
-        raise ValueError(f"fs ({fs}) 必须大于 0")
-    if order <= 0:
-        raise ValueError(f"滤波器阶数 ({order}) 必须大于 0")
-    if lowcut <= 0 or highcut <= 0:
-        raise ValueError("截止频率必须大于 0")
-    if lowcut >= highcut:
-        raise ValueError(f"lowcut ({lowcut}) 必须小于 highcut ({highcut})")
-    if highcut >= fs / 2:
-        raise ValueError(f"highcut ({highcut}) 必须小于奈奎斯特频率 ({fs / 2})")
-    sos = butter(order, [lowcut, highcut], btype="band", output="sos", fs=fs)
-    n_sections = int(sos.shape[0])
-    padlen = 3 * (2 * n_sections + 1 - min(int((sos[:, 2] == 0).sum()), int((sos[:, 5] == 0).sum())))
-    return sos, sosfilt_zi(sos), padlen
 
 
 def _view_records(records: np.ndarray) -> np.ndarray:
