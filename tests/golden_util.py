@@ -23,7 +23,7 @@ def grouping_case_names():
 
 
 def peaks_case_names():
-    return [n for n in case_names(prefix_exclude=()) if n.startswith(("peaks_", "dense_"))]
+    return [n for n in case_names(prefix_exclude=()) if n.startswith("peaks_")]
 
 
 def load_peaks(name):
