@@ -179,6 +179,42 @@ int wfa_waveform_width(wfa_ctx* ctx, int source, int64_t n_hits, const int64_t* 
                        double rise_high, double fall_high, double fall_low, double sampling_rate,
                        int interpolation, void* out_rows, uint8_t* valid);
 
+/* ---- hit-table stages (device sort + scans; host columns in, host index tables out) ----------------------
+ * K11 hit merge (reference: cpu/hit_merge.py:115-181 `_build_merged_clusters`, 256-322 `_emit_cluster`).
+ * Input: the columns of a hit table (THRESHOLD_HIT_DTYPE or its renamed variants).
+ * count/fill = HitMergeClustersPlugin: per hardware channel (ascending board, channel) hits are ordered by
+ * abs_start = ts + (edge_start - position) * dt * 1e3 (float64, stable) and chained while merge_gap_ns > 0, dt
+ * unchanged, gap <= merge_gap and total width <= max_total_width.  fill: order[n] = hit index of each
+ * cluster-ordered row (= hit_merge_clusters.hit_index) and cluster_offset[n_clusters + 1] into it.
+ * emit = the per-cluster part of HitMergePlugin for ANY membership table (as the reference derives hit_merged
+ * from whatever hit_merge_clusters holds): anchor hit index (max height, tie -> smallest timestamp, first such),
+ * max height, sum of integrals (numpy's pairwise float64 order, as float32), min/max sample window (-1, -1 if the
+ * cluster spans records) and width (-1 likewise). */
+int wfa_hit_merge_count(wfa_ctx* ctx, int64_t n_hits, const int64_t* timestamp, const int64_t* position,
+                        const int32_t* edge_start, const int32_t* edge_end, const int32_t* dt, const int16_t* board,
+                        const int16_t* channel, double merge_gap_ns, double max_total_width_ns, int64_t* n_clusters);
+int wfa_hit_merge_fill(wfa_ctx* ctx, int64_t n_hits, int64_t n_clusters, int64_t* order, int64_t* cluster_offset);
+int wfa_hit_merge_emit(wfa_ctx* ctx, int64_t n_hits, const int64_t* timestamp, const int32_t* sample_start,
+                       const int32_t* sample_end, const int64_t* record_id, const float* height, const float* integral,
+                       int64_t n_members, const int64_t* member_hit, int64_t n_clusters, const int64_t* cluster_offset,
+                       int64_t* anchor, float* out_height, float* out_integral, int32_t* out_start, int32_t* out_end,
+                       float* out_width);
+
+/* K9 event grouping (reference: processing/event_grouping.py:286-471 `group_hit_windows`).  Absolute windows as
+ * above from (sample_start, sample_end); global order np.lexsort((record_id, timestamp, dt, abs_start)); a hit
+ * opens a new event when abs_start > running max(abs_end) + time_window_ns * 1e3; inside an event hits are ordered
+ * by (board, channel, dt, abs_start, timestamp, record_id).  abs_*_fix (both or neither, may be NULL): where not
+ * NaN they replace the computed window (merged hits spanning records take the extent of their components,
+ * event_grouping.py:371-416).  fill: order[n] (hit indices, event-major),
+ * event_start[n_events + 1], t_min / t_max = int(min abs_start) / int(max abs_end) per event (ps). */
+int wfa_group_hit_windows_count(wfa_ctx* ctx, int64_t n_hits, const int64_t* timestamp, const int64_t* position,
+                                const int32_t* sample_start, const int32_t* sample_end, const int32_t* dt,
+                                const int16_t* board, const int16_t* channel, const int64_t* record_id,
+                                const double* abs_start_fix, const double* abs_end_fix, double time_window_ns,
+                                int64_t* n_events);
+int wfa_group_hit_windows_fill(wfa_ctx* ctx, int64_t n_hits, int64_t n_events, int64_t* order, int64_t* event_start,
+                               int64_t* t_min, int64_t* t_max);
+
 /* K6 integral-quantile width (reference: waveform_width_integral.py:166-227).
  * out: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B). */
 int wfa_width_integral(wfa_ctx* ctx, int source, double q_low, double q_high, double dt,

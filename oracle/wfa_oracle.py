@@ -662,3 +662,80 @@ def s1_s2_classify(widths: np.ndarray, features: np.ndarray, *, width_unit="ns",
         rows.append((label, wn, ws, h, a, int(w["timestamp"]), int(w["board"]) if "board" in w.dtype.names else 0,
                      int(w["channel"]), rid, int(w["peak_position"])))
     return np.array(rows, dtype=S1_S2_CLASSIFIER_DTYPE) if rows else np.zeros(0, dtype=S1_S2_CLASSIFIER_DTYPE)
+
+
+# ------------------------------------------------------------------------------------------------
+# Hit merging (cpu/hit_merge.py), literal loops over python lists as the reference walks them
+# ------------------------------------------------------------------------------------------------
+HIT_MERGED_DTYPE = np.dtype(
+    [("position", "i8"), ("height", "f4"), ("integral", "f4"), ("sample_start", "i4"), ("sample_end", "i4"),
+     ("width", "f4"), ("dt", "i4"), ("rise_time", "f4"), ("fall_time", "f4"), ("timestamp", "i8"), ("board", "i2"),
+     ("channel", "i2"), ("record_id", "i8"), ("component_offset", "i8"), ("component_count", "i4")]
+)
+HIT_MERGE_CLUSTERS_DTYPE = np.dtype([("cluster_index", "i8"), ("hit_index", "i8")])
+
+
+def hit_merge_clusters(hits: np.ndarray, merge_gap_ns: float = 0.0, max_total_width_ns: float = 10000.0) -> list:
+    """hit_merge.py:115-181: list of clusters, each a list of hit indices in chain order."""
+    if len(hits) == 0:
+        return []
+    boards = hits["board"].astype(np.int64) if "board" in hits.dtype.names else np.zeros(len(hits), dtype=np.int64)
+    channels = hits["channel"].astype(np.int64)
+    dt_ps = hits["dt"].astype(np.float64) * 1e3
+    abs0 = hits["timestamp"].astype(np.float64) + (hits["edge_start"].astype(np.float64) - hits["position"].astype(np.float64)) * dt_ps
+    abs1 = hits["timestamp"].astype(np.float64) + (hits["edge_end"].astype(np.float64) - hits["position"].astype(np.float64)) * dt_ps
+    gap_ps, cap_ps = merge_gap_ns * 1e3, max_total_width_ns * 1e3
+    clusters = []
+    for b, c in sorted(set(zip(boards.tolist(), channels.tolist()))):
+        idx = np.flatnonzero((boards == b) & (channels == c))
+        idx = idx[np.argsort(abs0[idx], kind="mergesort")]
+        current = [int(idx[0])]
+        c_start, c_end = abs0[idx[0]], abs1[idx[0]]
+        for i in idx[1:]:
+            i = int(i)
+            nxt = max(c_end, abs1[i])
+            if (merge_gap_ns > 0 and dt_ps[i] == dt_ps[current[-1]] and abs0[i] - c_end <= gap_ps
+                    and nxt - c_start <= cap_ps):
+                current.append(i)
+                c_end = nxt
+            else:
+                clusters.append(current)
+                current = [i]
+                c_start, c_end = abs0[i], abs1[i]
+        clusters.append(current)
+    return clusters
+
+
+def hit_merge_cluster_rows(clusters: list) -> np.ndarray:
+    rows = [(k, i) for k, members in enumerate(clusters) for i in members]
+    return np.array(rows, dtype=HIT_MERGE_CLUSTERS_DTYPE) if rows else np.zeros(0, dtype=HIT_MERGE_CLUSTERS_DTYPE)
+
+
+def hit_merged_rows(hits: np.ndarray, clusters: list) -> np.ndarray:
+    """hit_merge.py:256-322 per cluster."""
+    rows = []
+    offset = 0
+    for members in clusters:
+        sub = hits[members]
+        if len(members) == 1:
+            h = sub[0]
+            rows.append((int(h["position"]), float(h["height"]), float(h["integral"]), int(h["edge_start"]),
+                         int(h["edge_end"]), float(h["width"]), int(h["dt"]), float(h["rise_time"]), float(h["fall_time"]),
+                         int(h["timestamp"]), int(h["board"]), int(h["channel"]), int(h["record_id"]), offset, 1))
+            offset += 1
+            continue
+        heights = sub["height"].astype(np.float64)
+        top = float(np.max(heights))
+        tied = [k for k in range(len(members)) if float(heights[k]) == top]
+        a = sub[min(tied, key=lambda k: int(sub["timestamp"][k]))]
+        if len(set(sub["record_id"].tolist())) == 1:
+            s0, s1 = int(sub["edge_start"].min()), int(sub["edge_end"].max())
+        else:
+            s0 = s1 = -1
+        width = -1.0 if (s0 < 0 or s1 < 0) else float(max(s1 - s0, 0.0))
+        total = float(np.sum([float(v) for v in sub["integral"]]))
+        rows.append((int(a["position"]), top, total, s0, s1, width, int(a["dt"]), float(a["rise_time"]),
+                     float(a["fall_time"]), int(a["timestamp"]), int(a["board"]), int(a["channel"]), int(a["record_id"]),
+                     offset, len(members)))
+        offset += len(members)
+    return np.array(rows, dtype=HIT_MERGED_DTYPE) if rows else np.zeros(0, dtype=HIT_MERGED_DTYPE)

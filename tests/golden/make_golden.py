@@ -246,6 +246,80 @@ def dense_case(name, records, pool, *, filter_cc, width_cfgs, s1s2_cfgs):
           f"-> {os.path.getsize(path)} B")
 
 
+def crafted_hits(seed, n, n_records=60):
+    """THRESHOLD_HIT_DTYPE rows whose records abut in time, so chains cross record boundaries; few distinct
+    heights (anchor ties), two sample intervals, unsorted input order."""
+    from waveform_analysis.core.plugins.builtin.cpu.hit_finder import THRESHOLD_HIT_DTYPE
+
+    rng = np.random.default_rng(seed)
+    L = 200
+    rec_channel = rng.integers(0, 3, n_records)
+    rec_board = rng.integers(0, 2, n_records)
+    rec_dt = np.where(rng.random(n_records) < 0.85, 4, 2)
+    rec_ts = np.zeros(n_records, dtype=np.int64)
+    for key in set(zip(rec_board.tolist(), rec_channel.tolist())):
+        idx = np.flatnonzero((rec_board == key[0]) & (rec_channel == key[1]))
+        gaps = rng.choice([0, 0, 40, 400, 30000], size=len(idx)) * 1000
+        rec_ts[idx] = 10**9 + np.cumsum(L * rec_dt[idx] * 1000 + gaps)
+    hits = np.zeros(n, dtype=THRESHOLD_HIT_DTYPE)
+    rid = rng.integers(0, n_records, n)
+    start = rng.integers(0, L - 12, n)
+    width = rng.integers(1, 12, n)
+    pos = start + rng.integers(0, width)
+    hits["record_id"] = rid
+    hits["edge_start"] = start
+    hits["edge_end"] = start + width
+    hits["position"] = pos
+    hits["width"] = width
+    hits["dt"] = rec_dt[rid]
+    hits["board"] = rec_board[rid]
+    hits["channel"] = rec_channel[rid]
+    hits["timestamp"] = rec_ts[rid] + pos * rec_dt[rid] * 1000
+    hits["height"] = rng.choice([12.0, 12.0, 30.5, 77.25, 140.0], n)
+    hits["integral"] = rng.uniform(5, 900, n).astype(np.float32)
+    hits["rise_time"] = (pos - start) * rec_dt[rid]
+    hits["fall_time"] = (start + width - 1 - pos) * rec_dt[rid]
+    return hits
+
+
+def merge_case(name, hits, configs, windows=(0, 100, 5000)):
+    """Reference HitMergeClustersPlugin / HitMergePlugin / HitMergedComponentsPlugin (cpu/hit_merge.py:325-544) and
+    group_hit_windows on the merged rows with their components (event_grouping.py:286-471)."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.plugins.builtin.cpu.hit_merge import (
+        HitMergeClustersPlugin,
+        HitMergedComponentsPlugin,
+        HitMergePlugin,
+    )
+    from waveform_analysis.core.processing.event_grouping import group_hit_windows
+
+    out = {"hits": hits, "windows": np.asarray(windows, dtype=np.float64)}
+    sizes = []
+    for k, cfg in enumerate(configs):
+        data = {"hit_threshold": hits}
+        clusters = HitMergeClustersPlugin().compute(Ctx(dict(cfg), data), "run")
+        data["hit_merge_clusters"] = clusters
+        merged = HitMergePlugin().compute(Ctx(dict(cfg), data), "run")
+        data["hit_merged"] = merged
+        comps = HitMergedComponentsPlugin().compute(Ctx(dict(cfg), data), "run")
+        out[f"clusters_{k}"], out[f"merged_{k}"], out[f"components_{k}"] = clusters, merged, comps
+        sizes.append((len(merged), int((merged["component_count"] > 1).sum()), int((merged["sample_start"] < 0).sum())))
+        for tw in windows:
+            df = group_hit_windows(merged, time_window_ns=float(tw), component_rows=comps, component_hits=hits)
+            tag = f"g{k}_w{int(tw)}"
+            out[f"{tag}_t_min"] = df["t_min"].to_numpy(dtype=np.int64)
+            out[f"{tag}_t_max"] = df["t_max"].to_numpy(dtype=np.int64)
+            out[f"{tag}_n_hits"] = df["n_hits"].to_numpy(dtype=np.int64)
+            for col in ("dt", "boards", "channels", "heights", "integrals", "timestamps", "record_ids", "sample_starts",
+                        "sample_ends"):
+                out[f"{tag}_{col}"] = np.concatenate(list(df[col])) if len(df) else np.zeros(0)
+    out["options_json"] = np.frombuffer(json.dumps(list(configs)).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(hits)} hits -> (merged, multi, spanning) {sizes} -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -388,6 +462,15 @@ def main():
         ctx = Ctx({"wave_source": "records", "threshold": 15.0}, {"records": rec, "wave_pool": pool})
         hits = ThresholdHitPlugin().compute(ctx, "run")
         grouping_case(f"grouping_{preset}", hits, (0, 100, 5000, 2000000))
+
+    # hit merging: real threshold hits of a 16-channel run, and crafted hits whose chains cross records
+    merge_cfgs = [{}, {"merge_gap_ns": 20.0}, {"merge_gap_ns": 400.0, "max_total_width_ns": 1500.0},
+                  {"merge_gap_ns": 5000.0, "max_total_width_ns": 1e9}]
+    rec, pool = synth.make_run(90, "v1725", cfg=18)
+    ctx = Ctx({"wave_source": "records", "threshold": 6.0, "left_extension": 1, "right_extension": 1},
+              {"records": rec, "wave_pool": pool})
+    merge_case("merge_v1725", ThresholdHitPlugin().compute(ctx, "run"), merge_cfgs)
+    merge_case("merge_crafted", crafted_hits(5, 700), merge_cfgs)
 
     # large timestamps (float64 rounding of the hit timestamp), saturated + near-zero samples
     rec, pool = synth.make_run(16, "v1725", cfg=4)

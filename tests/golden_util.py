@@ -49,6 +49,17 @@ def load_dense(name):
     return d
 
 
+def merge_case_names():
+    return sorted(os.path.splitext(f)[0] for f in os.listdir(GOLDEN) if f.startswith("merge_") and f.endswith(".npz"))
+
+
+def load_merge(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["configs"] = json.loads(bytes(d.pop("options_json")).decode())
+    return d
+
+
 def load_grouping(name):
     z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}

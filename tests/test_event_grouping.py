@@ -1,5 +1,5 @@
-"""Event grouping (group_hit_windows): vectorised implementation vs the reference's DataFrames
-(golden fixtures) and vs the oracle's literal loop on other inputs."""
+"""Event grouping (group_hit_windows): the device sort/scan implementation vs the reference's DataFrames
+(golden fixtures) and vs the oracle's literal loop on other inputs; validation errors need no device."""
 
 import numpy as np
 import pytest
@@ -12,6 +12,7 @@ from waveformanalysis_amd.event_grouping import EVENT_COLUMNS, group_hit_windows
 COLS = ("dt", "boards", "channels", "heights", "integrals", "timestamps", "record_ids", "sample_starts", "sample_ends")
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", G.grouping_case_names())
 def test_matches_reference_dataframe(name):
     case = G.load_grouping(name)
@@ -31,6 +32,7 @@ def test_matches_reference_dataframe(name):
             assert got.dtype == case[f"{tag}_{col}"].dtype
 
 
+@pytest.mark.gpu
 def test_flat_form_equals_literal_loop():
     rec, pool = synth.make_run(300, "vx2730", cfg=12, threads=1)
     hits = O.threshold_hits_chunked(rec, pool, threshold=12.0)

@@ -348,6 +348,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : c->ht) b.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -107,6 +107,11 @@ struct wfa_ctx {
     int64_t n_peaks = -1;
     wfa::DevBuf peak_cand_n, peak_cand_pos, peak_cand_val, peak_cand_state;  // distance > 2: candidate lists
     wfa::DevBuf wh_pos, wh_row, wh_valid;  // per-hit inputs of k_waveform_width
+    // hit-table stages (wfa_hits.hip): scratch slots and the state of the last count pass
+    wfa::DevBuf ht[40];
+    int64_t ht_n = -1, ht_groups = 0;
+    int ht_kind = 0;  // 1 = event grouping, 2 = hit merge
+    int64_t* ht_perm = nullptr;
     wfa::DevBuf bw_scratch;  // float64 forward pass of sosfiltfilt, [sample][record-in-batch]
 
     // profiling

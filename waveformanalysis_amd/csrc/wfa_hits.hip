@@ -1,0 +1,505 @@
+// Hit-table stages on the device: hit merging (cpu/hit_merge.py) and event grouping
+// (processing/event_grouping.py:286-471).  These are the reduce steps after the sample kernels: tables of
+// 10^5..10^7 hit rows, sorted with rocPRIM's stable radix sort (through hipCUB) and reduced with scans and
+// small per-group / per-cluster kernels.  Multi-key orders are built the way np.lexsort defines them:
+// stable sorts from the least significant key to the most significant one.
+#include <hipcub/hipcub.hpp>
+
+#include "wfa_common.hpp"
+#include "wfa_numpy.hpp"
+
+namespace wfa {
+namespace {
+
+constexpr int kTB = 256;
+
+__device__ __forceinline__ uint64_t ord_f64(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ uint64_t ord_i64(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kTB - 1) / kTB); }
+
+// ---- scratch slots of wfa_ctx::ht ------------------------------------------------------------------------
+enum Slot {
+    S_TS, S_POS, S_START, S_END, S_DT, S_BOARD, S_CHAN, S_RID, S_HEIGHT, S_INTEGRAL,
+    S_ABS0, S_ABS1, S_K0, S_K1, S_K2, S_K3, S_K4, S_KTMP0, S_KTMP1, S_PERM0, S_PERM1, S_CUB,
+    S_F0, S_F1, S_FLAG, S_ID, S_OUT0, S_OUT1, S_OUT2, S_OUT3, S_OUT4, S_OUT5, S_OUT6, S_OUT7, S_CNT, S_SG, S_N
+};
+static_assert(S_N <= 40, "wfa_ctx::ht is too small");
+
+template <typename T>
+int slot(wfa_ctx* c, int s, int64_t n, T** out) {
+    int rc = c->ht[s].ensure((size_t)(n > 0 ? n : 1) * sizeof(T));
+    if (rc) return rc;
+    *out = c->ht[s].as<T>();
+    return WFA_OK;
+}
+
+template <typename T>
+int upload(wfa_ctx* c, int s, const T* host, int64_t n, T** dev) {
+    int rc = slot<T>(c, s, n, dev);
+    if (rc) return rc;
+    if (n > 0) WFA_HIP_CHECK(hipMemcpyAsync(*dev, host, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return WFA_OK;
+}
+
+__global__ void k_iota(int64_t n, int64_t* p) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+__global__ void k_gather_u64(int64_t n, const uint64_t* __restrict__ src, const int64_t* __restrict__ perm,
+                             uint64_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+// perm <- the stable lexicographic order of keys[0] (primary), keys[1], ... ; returns the buffer holding it
+int lexsort(wfa_ctx* c, int64_t n, const uint64_t* const* keys, int n_keys, int64_t** perm_out) {
+    int rc;
+    int64_t *p0, *p1;
+    uint64_t *k0, *k1;
+    if ((rc = slot<int64_t>(c, S_PERM0, n, &p0)) || (rc = slot<int64_t>(c, S_PERM1, n, &p1))) return rc;
+    if ((rc = slot<uint64_t>(c, S_KTMP0, n, &k0)) || (rc = slot<uint64_t>(c, S_KTMP1, n, &k1))) return rc;
+    if (n > 0x7fffffff) return fail(WFA_E_LIMIT, "hit table has %lld rows; the device sort handles < 2^31", (long long)n);
+    hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, p0);
+    hipcub::DoubleBuffer<uint64_t> kb(k0, k1);
+    hipcub::DoubleBuffer<int64_t> pb(p0, p1);
+    size_t tmp_bytes = 0;
+    WFA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, pb, (int)n, 0, 64, c->stream));
+    if ((rc = c->ht[S_CUB].ensure(tmp_bytes))) return rc;
+    for (int k = n_keys - 1; k >= 0; --k) {
+        hipLaunchKernelGGL(k_gather_u64, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, keys[k], pb.Current(), kb.Current());
+        size_t tb = c->ht[S_CUB].cap;
+        WFA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->ht[S_CUB].ptr, tb, kb, pb, (int)n, 0, 64, c->stream));
+    }
+    WFA_HIP_CHECK(hipGetLastError());
+    *perm_out = pb.Current();
+    return WFA_OK;
+}
+
+struct MaxF64 {
+    __device__ double operator()(double a, double b) const { return b > a ? b : a; }
+};
+
+// ---- shared prep: absolute windows and sort keys ------------------------------------------------------------
+struct HitCols {
+    const int64_t* ts;
+    const int64_t* pos;
+    const int32_t* s;
+    const int32_t* e;
+    const int32_t* dt;
+    const int16_t* board;
+    const int16_t* chan;
+    const int64_t* rid;
+};
+
+// abs = float(timestamp) + (float(edge) - float(position)) * (float(dt) * 1e3)
+// (hit_merge.py:75-82, event_grouping.py:365-367; no contraction: the build uses -ffp-contract=off)
+__global__ void k_hit_prep(int64_t n, HitCols h, const double* __restrict__ fix0, const double* __restrict__ fix1,
+                           double* __restrict__ abs0, double* __restrict__ abs1,
+                           uint64_t* __restrict__ k_abs0, uint64_t* __restrict__ k_dt, uint64_t* __restrict__ k_ts,
+                           uint64_t* __restrict__ k_rid, uint64_t* __restrict__ k_chan) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    const double t = (double)h.ts[i], p = (double)h.pos[i], dps = (double)h.dt[i] * 1e3;
+    double a0 = t + ((double)h.s[i] - p) * dps, a1 = t + ((double)h.e[i] - p) * dps;
+    if (fix0 && fix0[i] == fix0[i]) a0 = fix0[i];
+    if (fix1 && fix1[i] == fix1[i]) a1 = fix1[i];
+    abs0[i] = a0;
+    abs1[i] = a1;
+    k_abs0[i] = ord_f64(a0);
+    if (k_dt) k_dt[i] = (uint64_t)(uint32_t)h.dt[i];
+    if (k_ts) k_ts[i] = ord_i64(h.ts[i]);
+    if (k_rid) k_rid[i] = ord_i64(h.rid[i]);
+    // (board, channel[, dt]) ascending as signed integers
+    const uint64_t bc = ((uint64_t)(uint16_t)(h.board[i] ^ (int16_t)0x8000) << 48) |
+                        ((uint64_t)(uint16_t)(h.chan[i] ^ (int16_t)0x8000) << 32);
+    k_chan[i] = k_dt ? (bc | (uint64_t)(uint32_t)h.dt[i]) : bc;
+}
+
+int upload_cols(wfa_ctx* c, int64_t n, const int64_t* ts, const int64_t* pos, const int32_t* s, const int32_t* e,
+                const int32_t* dt, const int16_t* board, const int16_t* chan, const int64_t* rid, HitCols* h) {
+    int rc;
+    int64_t *d_ts, *d_pos, *d_rid;
+    int32_t *d_s, *d_e, *d_dt;
+    int16_t *d_b, *d_c;
+    if ((rc = upload(c, S_TS, ts, n, &d_ts)) || (rc = upload(c, S_POS, pos, n, &d_pos)) ||
+        (rc = upload(c, S_START, s, n, &d_s)) || (rc = upload(c, S_END, e, n, &d_e)) ||
+        (rc = upload(c, S_DT, dt, n, &d_dt)) || (rc = upload(c, S_BOARD, board, n, &d_b)) ||
+        (rc = upload(c, S_CHAN, chan, n, &d_c)) || (rc = upload(c, S_RID, rid, n, &d_rid)))
+        return rc;
+    *h = HitCols{d_ts, d_pos, d_s, d_e, d_dt, d_b, d_c, d_rid};
+    return WFA_OK;
+}
+
+// ---- event grouping ---------------------------------------------------------------------------------------
+__global__ void k_gather_f64(int64_t n, const double* __restrict__ src, const int64_t* __restrict__ perm,
+                             double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+// a hit opens a new event <=> its start lies more than `gap` after the latest end seen so far (:457-470)
+__global__ void k_event_flags(int64_t n, const double* __restrict__ abs0, const int64_t* __restrict__ perm,
+                              const double* __restrict__ run_max, double gap_ps, int64_t* __restrict__ flag) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    flag[j] = (j == 0 || abs0[perm[j]] > run_max[j - 1] + gap_ps) ? 1 : 0;
+}
+
+__global__ void k_event_keys(int64_t n, const int64_t* __restrict__ perm, const int64_t* __restrict__ incl,
+                             uint64_t* __restrict__ k_event) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j < n) k_event[perm[j]] = (uint64_t)(incl[j] - 1);
+}
+
+__global__ void k_event_starts(int64_t n, const uint64_t* __restrict__ k_event, const int64_t* __restrict__ perm,
+                               int64_t n_events, int64_t* __restrict__ event_start) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t ev = k_event[perm[j]];
+    if (j == 0 || k_event[perm[j - 1]] != ev) event_start[ev] = j;
+    if (j == n - 1) event_start[n_events] = n;
+}
+
+__global__ void k_event_minmax(int64_t n_events, const int64_t* __restrict__ event_start,
+                               const int64_t* __restrict__ perm, const double* __restrict__ abs0,
+                               const double* __restrict__ abs1, int64_t* __restrict__ t_min,
+                               int64_t* __restrict__ t_max) {
+    const int64_t ev = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (ev >= n_events) return;
+    const int64_t a = event_start[ev], b = event_start[ev + 1];
+    double lo = abs0[perm[a]], hi = abs1[perm[a]];
+    for (int64_t j = a + 1; j < b; ++j) {
+        const double s = abs0[perm[j]], e = abs1[perm[j]];
+        lo = s < lo ? s : lo;
+        hi = e > hi ? e : hi;
+    }
+    t_min[ev] = (int64_t)lo;  // int(np.min(...)): truncation
+    t_max[ev] = (int64_t)hi;
+}
+
+// ---- hit merge --------------------------------------------------------------------------------------------
+__global__ void k_merge_gather(int64_t n, const int64_t* __restrict__ perm, const double* __restrict__ abs0,
+                               const double* __restrict__ abs1, const int32_t* __restrict__ dt,
+                               const uint64_t* __restrict__ k_chan, double* __restrict__ s0, double* __restrict__ s1,
+                               int32_t* __restrict__ sdt, uint64_t* __restrict__ sg) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    const int64_t i = perm[j];
+    s0[j] = abs0[i]; s1[j] = abs1[i]; sdt[j] = dt[i]; sg[j] = k_chan[i];
+}
+
+__global__ void k_merge_heads(int64_t n, const uint64_t* __restrict__ sg, int64_t* __restrict__ heads,
+                              unsigned long long* __restrict__ n_heads) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0 || sg[j] != sg[j - 1]) heads[atomicAdd(n_heads, 1ull)] = j;
+}
+
+// the chain of hit_merge.py:151-179, one lane per hardware channel (the max-total-width cap makes the chain
+// a genuinely sequential greedy segmentation; channels are independent)
+__global__ void k_merge_chain(int64_t n, const unsigned long long* __restrict__ n_heads, const int64_t* __restrict__ heads,
+                              const double* __restrict__ s0, const double* __restrict__ s1,
+                              const int32_t* __restrict__ sdt, const uint64_t* __restrict__ sg, int do_merge,
+                              double gap_ps, double max_width_ps, int64_t* __restrict__ flag) {
+    const int64_t g = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (g >= (int64_t)*n_heads) return;
+    int64_t j = heads[g];
+    const uint64_t grp = sg[j];
+    double c_start = s0[j], c_end = s1[j];
+    int32_t prev_dt = sdt[j];
+    flag[j] = 1;
+    for (++j; j < n && sg[j] == grp; ++j) {
+        const double a = s0[j], e = s1[j];
+        const double gap = a - c_end;
+        const double next_end = e > c_end ? e : c_end;
+        const double total = next_end - c_start;
+        const bool same_dt = sdt[j] == prev_dt;
+        if (do_merge && same_dt && gap <= gap_ps && total <= max_width_ps) {
+            flag[j] = 0;
+            c_end = next_end;
+        } else {
+            flag[j] = 1;
+            c_start = a;
+            c_end = e;
+        }
+        prev_dt = sdt[j];
+    }
+}
+
+__global__ void k_cluster_offsets(int64_t n, const int64_t* __restrict__ flag, const int64_t* __restrict__ incl,
+                                  int64_t n_clusters, int64_t* __restrict__ offset) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    if (flag[j]) offset[incl[j] - 1] = j;
+    if (j == n - 1) offset[n_clusters] = n;
+}
+
+// _emit_cluster (hit_merge.py:256-322) for every cluster; singles are flagged and copied on the host
+__global__ void k_merge_emit(int64_t n_clusters, const int64_t* __restrict__ offset, const int64_t* __restrict__ perm,
+                             HitCols h, const float* __restrict__ height, const float* __restrict__ integral,
+                             int64_t* __restrict__ anchor, float* __restrict__ out_h, float* __restrict__ out_int,
+                             int32_t* __restrict__ out_s, int32_t* __restrict__ out_e, float* __restrict__ out_w) {
+    const int64_t cl = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (cl >= n_clusters) return;
+    const int64_t a = offset[cl], b = offset[cl + 1];
+    int64_t best = perm[a];
+    double max_h = (double)height[best];
+    for (int64_t j = a + 1; j < b; ++j) {
+        const double v = (double)height[perm[j]];
+        if (v > max_h) max_h = v;  // np.max
+    }
+    // anchor: the member with the maximum height; ties -> the smallest timestamp, first such member
+    bool have = false;
+    for (int64_t j = a; j < b; ++j) {
+        const int64_t i = perm[j];
+        if ((double)height[i] != max_h) continue;
+        if (!have || h.ts[i] < h.ts[best]) { best = i; have = true; }
+    }
+    int32_t smin = h.s[perm[a]], emax = h.e[perm[a]];
+    bool one_record = true;
+    const int64_t rid0 = h.rid[perm[a]];
+    for (int64_t j = a + 1; j < b; ++j) {
+        const int64_t i = perm[j];
+        smin = h.s[i] < smin ? h.s[i] : smin;
+        emax = h.e[i] > emax ? h.e[i] : emax;
+        one_record = one_record && h.rid[i] == rid0;
+    }
+    if (!one_record) { smin = -1; emax = -1; }
+    double w = (double)emax - (double)smin;  // python ints; max(.., 0.0)
+    w = w > 0.0 ? w : 0.0;
+    if (smin < 0 || emax < 0) w = -1.0;
+    const double total = np_pairwise_sum([&](int q) { return (double)integral[perm[a + q]]; }, 0, (int)(b - a));
+    anchor[cl] = best;
+    out_h[cl] = (float)max_h;
+    out_int[cl] = (float)total;
+    out_s[cl] = smin;
+    out_e[cl] = emax;
+    out_w[cl] = (float)w;
+}
+
+}  // namespace
+}  // namespace wfa
+
+using namespace wfa;
+
+static int use_device_ht(wfa_ctx* c) {
+    if (!c) return fail(WFA_E_INVALID, "ctx is null");
+    WFA_HIP_CHECK(hipSetDevice(c->device));
+    return WFA_OK;
+}
+
+extern "C" {
+
+int wfa_group_hit_windows_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const int64_t* position,
+                                const int32_t* sample_start, const int32_t* sample_end, const int32_t* dt,
+                                const int16_t* board, const int16_t* channel, const int64_t* record_id,
+                                const double* abs_start_fix, const double* abs_end_fix, double time_window_ns,
+                                int64_t* n_events) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n < 0 || !n_events) return fail(WFA_E_INVALID, "bad arguments");
+    if (time_window_ns < 0) return fail(WFA_E_INVALID, "time_window_ns must be >= 0");
+    c->ht_n = -1;
+    if (n == 0) { c->ht_n = 0; c->ht_groups = 0; c->ht_kind = 1; *n_events = 0; return WFA_OK; }
+    if (!timestamp || !position || !sample_start || !sample_end || !dt || !board || !channel || !record_id)
+        return fail(WFA_E_INVALID, "null column");
+    HitCols h{};
+    if ((rc = upload_cols(c, n, timestamp, position, sample_start, sample_end, dt, board, channel, record_id, &h))) return rc;
+    if ((abs_start_fix == nullptr) != (abs_end_fix == nullptr)) return fail(WFA_E_INVALID, "pass both abs_*_fix arrays or neither");
+    double *fix0 = nullptr, *fix1 = nullptr;
+    if (abs_start_fix && ((rc = upload(c, S_OUT6, abs_start_fix, n, &fix0)) || (rc = upload(c, S_OUT7, abs_end_fix, n, &fix1)))) return rc;
+    double *abs0, *abs1, *ends, *run_max;
+    uint64_t *k_abs, *k_dt, *k_ts, *k_rid, *k_chan, *k_ev;
+    int64_t *flag, *incl;
+    if ((rc = slot(c, S_ABS0, n, &abs0)) || (rc = slot(c, S_ABS1, n, &abs1)) || (rc = slot(c, S_K0, n, &k_abs)) ||
+        (rc = slot(c, S_K1, n, &k_dt)) || (rc = slot(c, S_K2, n, &k_ts)) || (rc = slot(c, S_K3, n, &k_rid)) ||
+        (rc = slot(c, S_K4, n, &k_chan)) || (rc = slot(c, S_F0, n, &ends)) || (rc = slot(c, S_F1, n, &run_max)) ||
+        (rc = slot(c, S_FLAG, n, &flag)) || (rc = slot(c, S_ID, n, &incl)))
+        return rc;
+    LaunchTimer t(c);
+    hipLaunchKernelGGL(k_hit_prep, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, h, (const double*)fix0, (const double*)fix1, abs0, abs1, k_abs, k_dt, k_ts, k_rid, k_chan);
+    int64_t* perm = nullptr;
+    {
+        const uint64_t* keys[4] = {k_abs, k_dt, k_ts, k_rid};  // np.lexsort((record_ids, timestamps, dt, abs_starts))
+        if ((rc = lexsort(c, n, keys, 4, &perm))) return rc;
+    }
+    hipLaunchKernelGGL(k_gather_f64, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, abs1, perm, ends);
+    size_t tb = 0;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, tb, ends, run_max, MaxF64(), (int)n, c->stream));
+    size_t tb2 = 0;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, flag, incl, (int)n, c->stream));
+    if ((rc = c->ht[S_CUB].ensure(tb > tb2 ? tb : tb2))) return rc;
+    tb = c->ht[S_CUB].cap;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(c->ht[S_CUB].ptr, tb, ends, run_max, MaxF64(), (int)n, c->stream));
+    hipLaunchKernelGGL(k_event_flags, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, abs0, perm, run_max,
+                       time_window_ns * 1e3, flag);
+    tb = c->ht[S_CUB].cap;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->ht[S_CUB].ptr, tb, flag, incl, (int)n, c->stream));
+    int64_t n_ev = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&n_ev, incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    // event id as the new primary key; k_dt's buffer is free again (k_chan carries dt)
+    k_ev = k_dt;
+    hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, perm, incl, k_ev);
+    {
+        // np.lexsort((record_ids, timestamps, abs_starts, dt, channels, boards, event_id))
+        const uint64_t* keys[5] = {k_ev, k_chan, k_abs, k_ts, k_rid};
+        if ((rc = lexsort(c, n, keys, 5, &perm))) return rc;
+    }
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int64_t *ev_start, *t_min, *t_max;
+    if ((rc = slot(c, S_OUT0, n_ev + 1, &ev_start)) || (rc = slot(c, S_OUT1, n_ev, &t_min)) || (rc = slot(c, S_OUT2, n_ev, &t_max)))
+        return rc;
+    hipLaunchKernelGGL(k_event_starts, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, k_ev, perm, n_ev, ev_start);
+    hipLaunchKernelGGL(k_event_minmax, dim3(blocks_for(n_ev)), dim3(kTB), 0, c->stream, n_ev, ev_start, perm, abs0, abs1, t_min, t_max);
+    WFA_HIP_CHECK(hipGetLastError());
+    if ((rc = t.end("hit table: group_hit_windows (sort + scans)"))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->ht_n = n; c->ht_groups = n_ev; c->ht_kind = 1; c->ht_perm = perm;
+    *n_events = n_ev;
+    return WFA_OK;
+}
+
+int wfa_group_hit_windows_fill(wfa_ctx* c, int64_t n, int64_t n_events, int64_t* order, int64_t* event_start,
+                               int64_t* t_min, int64_t* t_max) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (c->ht_n < 0 || c->ht_kind != 1) return fail(WFA_E_STATE, "no event grouping pass has been run");
+    if (n != c->ht_n || n_events != c->ht_groups)
+        return fail(WFA_E_INVALID, "caller expects %lld hits / %lld events, the pass produced %lld / %lld", (long long)n,
+                    (long long)n_events, (long long)c->ht_n, (long long)c->ht_groups);
+    if (!event_start) return fail(WFA_E_INVALID, "event_start is null");
+    if (n == 0) { event_start[0] = 0; return WFA_OK; }
+    if (!order || !t_min || !t_max) return fail(WFA_E_INVALID, "null output");
+    WFA_HIP_CHECK(hipMemcpyAsync(order, c->ht_perm, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(event_start, c->ht[S_OUT0].ptr, (size_t)(n_events + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(t_min, c->ht[S_OUT1].ptr, (size_t)n_events * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(t_max, c->ht[S_OUT2].ptr, (size_t)n_events * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_hit_merge_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const int64_t* position,
+                        const int32_t* edge_start, const int32_t* edge_end, const int32_t* dt, const int16_t* board,
+                        const int16_t* channel, double merge_gap_ns, double max_total_width_ns, int64_t* n_clusters) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n < 0 || !n_clusters) return fail(WFA_E_INVALID, "bad arguments");
+    c->ht_n = -1;
+    if (n == 0) { c->ht_n = 0; c->ht_groups = 0; c->ht_kind = 2; *n_clusters = 0; return WFA_OK; }
+    if (!timestamp || !position || !edge_start || !edge_end || !dt || !board || !channel)
+        return fail(WFA_E_INVALID, "null column");
+    HitCols h{};
+    if ((rc = upload_cols(c, n, timestamp, position, edge_start, edge_end, dt, board, channel, timestamp, &h))) return rc;
+    double *abs0, *abs1, *s0, *s1;
+    uint64_t *k_abs, *k_chan, *sg;
+    int32_t* sdt;
+    int64_t *flag, *incl, *heads;
+    unsigned long long* n_heads;
+    if ((rc = slot(c, S_ABS0, n, &abs0)) || (rc = slot(c, S_ABS1, n, &abs1)) || (rc = slot(c, S_K0, n, &k_abs)) ||
+        (rc = slot(c, S_K4, n, &k_chan)) || (rc = slot(c, S_F0, n, &s0)) || (rc = slot(c, S_F1, n, &s1)) ||
+        (rc = slot(c, S_K1, n, &sdt)) || (rc = slot(c, S_SG, n, &sg)) || (rc = slot(c, S_FLAG, n, &flag)) ||
+        (rc = slot(c, S_ID, n, &incl)) || (rc = slot(c, S_K2, n, &heads)) || (rc = slot(c, S_CNT, 1, &n_heads)))
+        return rc;
+    LaunchTimer t(c);
+    WFA_HIP_CHECK(hipMemsetAsync(n_heads, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_hit_prep, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, h, (const double*)nullptr,
+                       (const double*)nullptr, abs0, abs1, k_abs, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, k_chan);
+    int64_t* perm = nullptr;
+    {
+        // per hardware channel (ascending board, channel), stable by abs_start (hit_merge.py:137-149)
+        const uint64_t* keys[2] = {k_chan, k_abs};
+        if ((rc = lexsort(c, n, keys, 2, &perm))) return rc;
+    }
+    hipLaunchKernelGGL(k_merge_gather, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, perm, abs0, abs1, h.dt, k_chan, s0, s1, sdt, sg);
+    hipLaunchKernelGGL(k_merge_heads, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, sg, heads, n_heads);
+    // one lane per channel head; n lanes bound the head count
+    hipLaunchKernelGGL(k_merge_chain, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, n_heads, heads, s0, s1, sdt, sg,
+                       merge_gap_ns > 0 ? 1 : 0, merge_gap_ns * 1e3, max_total_width_ns * 1e3, flag);
+    size_t tb = 0;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb, flag, incl, (int)n, c->stream));
+    if ((rc = c->ht[S_CUB].ensure(tb))) return rc;
+    tb = c->ht[S_CUB].cap;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->ht[S_CUB].ptr, tb, flag, incl, (int)n, c->stream));
+    int64_t n_cl = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&n_cl, incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int64_t* offset;
+    if ((rc = slot(c, S_OUT0, n_cl + 1, &offset))) return rc;
+    hipLaunchKernelGGL(k_cluster_offsets, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, flag, incl, n_cl, offset);
+    WFA_HIP_CHECK(hipGetLastError());
+    if ((rc = t.end("hit table: hit_merge clusters (sort + chain)"))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->ht_n = n; c->ht_groups = n_cl; c->ht_kind = 2; c->ht_perm = perm;
+    *n_clusters = n_cl;
+    return WFA_OK;
+}
+
+int wfa_hit_merge_fill(wfa_ctx* c, int64_t n, int64_t n_clusters, int64_t* order, int64_t* cluster_offset) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (c->ht_n < 0 || c->ht_kind != 2) return fail(WFA_E_STATE, "no hit merge pass has been run");
+    if (n != c->ht_n || n_clusters != c->ht_groups)
+        return fail(WFA_E_INVALID, "caller expects %lld hits / %lld clusters, the pass produced %lld / %lld", (long long)n,
+                    (long long)n_clusters, (long long)c->ht_n, (long long)c->ht_groups);
+    if (!cluster_offset) return fail(WFA_E_INVALID, "cluster_offset is null");
+    if (n == 0) { cluster_offset[0] = 0; return WFA_OK; }
+    if (!order) return fail(WFA_E_INVALID, "order is null");
+    WFA_HIP_CHECK(hipMemcpyAsync(order, c->ht_perm, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(cluster_offset, c->ht[S_OUT0].ptr, (size_t)(n_clusters + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_hit_merge_emit(wfa_ctx* c, int64_t n, const int64_t* timestamp, const int32_t* sample_start,
+                       const int32_t* sample_end, const int64_t* record_id, const float* height, const float* integral,
+                       int64_t n_members, const int64_t* member_hit, int64_t n_clusters, const int64_t* cluster_offset,
+                       int64_t* anchor, float* out_height, float* out_integral, int32_t* out_start, int32_t* out_end,
+                       float* out_width) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n < 0 || n_members < 0 || n_clusters < 0) return fail(WFA_E_INVALID, "negative size");
+    if (n_clusters == 0) return WFA_OK;
+    if (!timestamp || !sample_start || !sample_end || !record_id || !height || !integral || !member_hit || !cluster_offset ||
+        !anchor || !out_height || !out_integral || !out_start || !out_end || !out_width)
+        return fail(WFA_E_INVALID, "null argument");
+    // membership must be well-formed before a kernel indexes with it
+    if (cluster_offset[0] != 0 || cluster_offset[n_clusters] != n_members) return fail(WFA_E_INVALID, "cluster_offset does not span the members");
+    for (int64_t k = 0; k < n_clusters; ++k)
+        if (cluster_offset[k + 1] <= cluster_offset[k]) return fail(WFA_E_INVALID, "empty or unordered cluster %lld", (long long)k);
+    for (int64_t j = 0; j < n_members; ++j)
+        if (member_hit[j] < 0 || member_hit[j] >= n) return fail(WFA_E_INVALID, "hit index %lld out of range", (long long)member_hit[j]);
+    HitCols h{};
+    int64_t *d_ts, *d_rid, *d_m, *d_off, *d_anchor;
+    int32_t *d_s, *d_e, *o_s, *o_e;
+    float *d_h, *d_i, *o_h, *o_i, *o_w;
+    if ((rc = upload(c, S_TS, timestamp, n, &d_ts)) || (rc = upload(c, S_START, sample_start, n, &d_s)) ||
+        (rc = upload(c, S_END, sample_end, n, &d_e)) || (rc = upload(c, S_RID, record_id, n, &d_rid)) ||
+        (rc = upload(c, S_HEIGHT, height, n, &d_h)) || (rc = upload(c, S_INTEGRAL, integral, n, &d_i)) ||
+        (rc = upload(c, S_PERM0, member_hit, n_members, &d_m)) || (rc = upload(c, S_OUT0, cluster_offset, n_clusters + 1, &d_off)))
+        return rc;
+    if ((rc = slot(c, S_OUT1, n_clusters, &d_anchor)) || (rc = slot(c, S_OUT2, n_clusters, &o_h)) || (rc = slot(c, S_OUT3, n_clusters, &o_i)) ||
+        (rc = slot(c, S_OUT4, n_clusters, &o_s)) || (rc = slot(c, S_OUT5, n_clusters, &o_e)) || (rc = slot(c, S_OUT6, n_clusters, &o_w)))
+        return rc;
+    h.ts = d_ts; h.s = d_s; h.e = d_e; h.rid = d_rid;
+    c->ht_n = -1;
+    LaunchTimer t(c);
+    hipLaunchKernelGGL(k_merge_emit, dim3(blocks_for(n_clusters)), dim3(kTB), 0, c->stream, n_clusters, d_off, d_m, h, d_h, d_i,
+                       d_anchor, o_h, o_i, o_s, o_e, o_w);
+    WFA_HIP_CHECK(hipGetLastError());
+    if ((rc = t.end("hit table: hit_merge emit"))) return rc;
+    const size_t m = (size_t)n_clusters;
+    WFA_HIP_CHECK(hipMemcpyAsync(anchor, d_anchor, m * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(out_height, o_h, m * 4, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(out_integral, o_i, m * 4, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(out_start, o_s, m * 4, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(out_end, o_e, m * 4, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(out_width, o_w, m * 4, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+}  // extern "C"

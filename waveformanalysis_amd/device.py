@@ -238,6 +238,66 @@ class DeviceSession:
             _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 
+    # ---- hit-table stages (device sort + scans) ------------------------------------------------------------
+    @staticmethod
+    def _hit_cols(timestamp, position, start, end, dt, board, channel, record_id):
+        cols = [np.ascontiguousarray(timestamp, dtype=np.int64), np.ascontiguousarray(position, dtype=np.int64),
+                np.ascontiguousarray(start, dtype=np.int32), np.ascontiguousarray(end, dtype=np.int32),
+                np.ascontiguousarray(dt, dtype=np.int32), np.ascontiguousarray(board, dtype=np.int16),
+                np.ascontiguousarray(channel, dtype=np.int16), np.ascontiguousarray(record_id, dtype=np.int64)]
+        n = len(cols[0])
+        if any(c.ndim != 1 or len(c) != n for c in cols):
+            raise ValueError("hit columns must be 1-D arrays of one length")
+        return n, cols
+
+    def hit_merge_clusters(self, timestamp, position, edge_start, edge_end, dt, board, channel,
+                           merge_gap_ns: float, max_total_width_ns: float) -> tuple[np.ndarray, np.ndarray]:
+        """Per-channel chain merge (hit_merge.py:115-181): (order, cluster_offset)."""
+        n, cols = self._hit_cols(timestamp, position, edge_start, edge_end, dt, board, channel, timestamp)
+        m = C.c_int64(0)
+        _lib.check(self._lib.wfa_hit_merge_count(self._h, n, *[_ptr(c) for c in cols[:7]], float(merge_gap_ns),
+                                                 float(max_total_width_ns), C.byref(m)))
+        order = np.empty(n, np.int64)
+        offset = np.empty(int(m.value) + 1, np.int64)
+        _lib.check(self._lib.wfa_hit_merge_fill(self._h, n, int(m.value), _ptr(order), _ptr(offset)))
+        return order, offset
+
+    def hit_merge_emit(self, timestamp, sample_start, sample_end, record_id, height, integral, member_hit,
+                       cluster_offset) -> dict:
+        """Per-cluster anchor / height / integral / sample window / width (hit_merge.py:256-322)."""
+        ts = np.ascontiguousarray(timestamp, dtype=np.int64)
+        s = np.ascontiguousarray(sample_start, dtype=np.int32)
+        e = np.ascontiguousarray(sample_end, dtype=np.int32)
+        rid = np.ascontiguousarray(record_id, dtype=np.int64)
+        h = np.ascontiguousarray(height, dtype=np.float32)
+        q = np.ascontiguousarray(integral, dtype=np.float32)
+        mem = np.ascontiguousarray(member_hit, dtype=np.int64)
+        off = np.ascontiguousarray(cluster_offset, dtype=np.int64)
+        n, k = len(ts), len(off) - 1
+        out = {"anchor": np.empty(k, np.int64), "height": np.empty(k, np.float32), "integral": np.empty(k, np.float32),
+               "sample_start": np.empty(k, np.int32), "sample_end": np.empty(k, np.int32), "width": np.empty(k, np.float32)}
+        _lib.check(self._lib.wfa_hit_merge_emit(self._h, n, _ptr(ts), _ptr(s), _ptr(e), _ptr(rid), _ptr(h), _ptr(q),
+                                                len(mem), _ptr(mem), k, _ptr(off),
+                                                *[_ptr(out[f]) for f in ("anchor", "height", "integral", "sample_start",
+                                                                        "sample_end", "width")]))
+        return out
+
+    def group_hit_windows(self, timestamp, position, sample_start, sample_end, dt, board, channel, record_id,
+                          time_window_ns: float, abs_start_fix=None, abs_end_fix=None) -> dict:
+        """Gap-chained event grouping (event_grouping.py:286-471): order, event_start, t_min, t_max."""
+        n, cols = self._hit_cols(timestamp, position, sample_start, sample_end, dt, board, channel, record_id)
+        f0 = None if abs_start_fix is None else np.ascontiguousarray(abs_start_fix, dtype=np.float64)
+        f1 = None if abs_end_fix is None else np.ascontiguousarray(abs_end_fix, dtype=np.float64)
+        m = C.c_int64(0)
+        _lib.check(self._lib.wfa_group_hit_windows_count(self._h, n, *[_ptr(c) for c in cols], _ptr(f0), _ptr(f1),
+                                                         float(time_window_ns), C.byref(m)))
+        k = int(m.value)
+        out = {"order": np.empty(n, np.int64), "event_start": np.empty(k + 1, np.int64),
+               "t_min": np.empty(k, np.int64), "t_max": np.empty(k, np.int64)}
+        _lib.check(self._lib.wfa_group_hit_windows_fill(self._h, n, k, _ptr(out["order"]), _ptr(out["event_start"]),
+                                                        _ptr(out["t_min"]), _ptr(out["t_max"])))
+        return out
+
     def basic_features(self, source: int = _lib.SRC_RAW, height_range=(40, 90), area_range=(0, None),
                        fixed_baseline: np.ndarray | None = None) -> np.ndarray:
         out = np.zeros(self.n_records, dtype=BASIC_FEATURES_DTYPE)

@@ -1,20 +1,17 @@
 """Event grouping of hit rows on the gathering rank (the one exchange step of the path).
 
-`group_hit_windows` is a vectorised restatement of the reference's
-waveform_analysis/core/processing/event_grouping.py:286-471 (`group_hit_windows`): absolute hit
-windows in float64 ps, a global lexsort, gap-chained clustering, and a per-event ordering.  The
-reference walks the sorted hits in a Python loop; here the chain is a running maximum:
+`group_hit_windows` follows waveform_analysis/core/processing/event_grouping.py:286-471: absolute hit windows
+in float64 ps, a global lexsort, gap-chained clustering and a per-event ordering.  The reference walks the
+sorted hits in a Python loop; here the chain is a running maximum,
 
     sorted by abs_start, a hit opens a new event  <=>  abs_start > max(abs_end of all earlier hits) + gap
 
-(the maximum over *all* earlier hits equals the maximum over the current cluster, because every
-earlier cluster ends more than `gap` before the current one starts), so event ids are a cumulative
-sum and the per-event ordering is one more lexsort with the event id as the primary key.
-Hits arrive from all GPUs through the RCCL gather (sharding.py / wfa_rccl_gather_rows).
-
-Merged hits whose window spans records (sample_start/end < 0, produced by hit_merge) need the
-component tables of the reference's `hit_merged_components`; that stage is not part of this backend
-yet, so such input raises the same ValueError as the reference does without components.
+(the maximum over *all* earlier hits equals the maximum over the current cluster, because every earlier cluster
+ends more than `gap` before the current one starts), so event ids are a prefix sum and the per-event ordering is
+one more lexsort with the event id as the primary key.  The two lexsorts (stable radix passes), the max-scan
+and the prefix sum run on the GPU (wfa_group_hit_windows_count / _fill); this module validates the table,
+resolves the windows of merged hits that span records from their components (event_grouping.py:369-416) and
+builds the ragged DataFrame.  Hits arrive from all GPUs through the RCCL gather (sharding.py).
 """
 
 from __future__ import annotations
@@ -35,7 +32,39 @@ def _window_fields(names: set[str]) -> tuple[str, str]:
     return "sample_start", "sample_end"
 
 
-def group_hit_windows_flat(hits: np.ndarray, time_window_ns: float, dt_values: np.ndarray | None = None) -> dict:
+def _component_windows(hits, names, invalid, component_rows, component_hits):
+    """abs window of merged hits without a sample window = extent of their component hits (:369-416)."""
+    if component_rows is None or component_hits is None:
+        raise ValueError("component_rows and component_hits are required when hit windows contain invalid edges")
+    hit_indices = np.asarray(component_rows["hit_index"], dtype=np.int64)
+    c_dt_ps = np.asarray(component_hits["dt"], dtype=np.int32).astype(np.float64) * 1e3
+    c_ts = np.asarray(component_hits["timestamp"], dtype=np.int64).astype(np.float64)
+    c_pos = np.asarray(component_hits["position"], dtype=np.float64)
+    c_abs0 = c_ts + (np.asarray(component_hits["edge_start"], dtype=np.int32) - c_pos) * c_dt_ps
+    c_abs1 = c_ts + (np.asarray(component_hits["edge_end"], dtype=np.int32) - c_pos) * c_dt_ps
+    fix0 = np.full(len(hits), np.nan)
+    fix1 = np.full(len(hits), np.nan)
+    have_table = "component_offset" in names and "component_count" in names
+    merged_indices = None if have_table else np.asarray(component_rows["merged_index"], dtype=np.int64)
+    for idx in np.flatnonzero(invalid):
+        if have_table:
+            off, cnt = int(hits["component_offset"][idx]), int(hits["component_count"][idx])
+            if cnt <= 0:
+                raise ValueError(f"missing hit_merged_components rows for hit_merged index {int(idx)}")
+            subset = hit_indices[off : off + cnt]
+        else:
+            mask = merged_indices == int(idx)
+            if not np.any(mask):
+                raise ValueError(f"missing hit_merged_components rows for hit_merged index {int(idx)}")
+            subset = hit_indices[mask]
+        fix0[idx] = float(np.min(c_abs0[subset]))
+        fix1[idx] = float(np.max(c_abs1[subset]))
+    return fix0, fix1
+
+
+def group_hit_windows_flat(hits: np.ndarray, time_window_ns: float, dt_values: np.ndarray | None = None,
+                           component_rows: np.ndarray | None = None, component_hits: np.ndarray | None = None,
+                           session=None) -> dict:
     """Flat form: `order` (hit indices, event-major, reference order inside an event),
     `event_start` (offsets into order, len = n_events + 1), `t_min`, `t_max` (int64 ps)."""
     if not isinstance(hits, np.ndarray):
@@ -65,48 +94,34 @@ def group_hit_windows_flat(hits: np.ndarray, time_window_ns: float, dt_values: n
         z = np.zeros(0, dtype=np.int64)
         return {"order": z, "event_start": np.zeros(1, dtype=np.int64), "t_min": z, "t_max": z, "dt": dt_values,
                 "start_name": start_name, "end_name": end_name}
-
-    timestamps = np.asarray(hits["timestamp"], dtype=np.int64)
-    positions = np.asarray(hits["position"], dtype=np.float64)
     s_rel = np.asarray(hits[start_name], dtype=np.int32)
     e_rel = np.asarray(hits[end_name], dtype=np.int32)
-    if np.any((s_rel < 0) | (e_rel < 0)):
-        raise ValueError("component_rows and component_hits are required when hit windows contain invalid edges")
-    record_ids = np.asarray(hits["record_id"], dtype=np.int64)
-    dt_ps = dt_values.astype(np.float64) * 1e3
-    abs_starts = timestamps.astype(np.float64) + (s_rel - positions) * dt_ps   # event_grouping.py:365-367
-    abs_ends = timestamps.astype(np.float64) + (e_rel - positions) * dt_ps
+    position = hits["position"]
+    if position.dtype.kind == "f":
+        raise ValueError("hit position must be an integer sample index")
+    invalid = (s_rel < 0) | (e_rel < 0)
+    fix0 = fix1 = None
+    if np.any(invalid):
+        fix0, fix1 = _component_windows(hits, names, invalid, component_rows, component_hits)
+    if session is None:
+        from .device import default_pool
 
-    order = np.lexsort((record_ids, timestamps, dt_values, abs_starts))          # :418
-    gap_ps = time_window_ns * 1e3
-    ends_sorted = abs_ends[order]
-    run_max = np.maximum.accumulate(ends_sorted)
-    new_event = np.ones(n, dtype=bool)
-    new_event[1:] = abs_starts[order][1:] > run_max[:-1] + gap_ps                # :457-470
-    event_of_sorted = np.cumsum(new_event) - 1
-    event_id = np.empty(n, dtype=np.int64)
-    event_id[order] = event_of_sorted
-
-    boards = np.asarray(hits["board"], dtype=np.int16)
-    channels = np.asarray(hits["channel"], dtype=np.int16)
-    inner = np.lexsort((record_ids, timestamps, abs_starts, dt_values, channels, boards, event_id))  # :423-432
-    n_events = int(event_of_sorted[-1]) + 1
-    counts = np.bincount(event_id, minlength=n_events)
-    event_start = np.zeros(n_events + 1, dtype=np.int64)
-    np.cumsum(counts, out=event_start[1:])
-    t_min = np.minimum.reduceat(abs_starts[inner], event_start[:-1]).astype(np.int64)  # int(np.min(...)) truncation
-    t_max = np.maximum.reduceat(abs_ends[inner], event_start[:-1]).astype(np.int64)
-    return {"order": inner, "event_start": event_start, "t_min": t_min, "t_max": t_max, "dt": dt_values,
-            "start_name": start_name, "end_name": end_name}
+        session = default_pool().session()
+    flat = session.group_hit_windows(hits["timestamp"], position, s_rel, e_rel, dt_values, hits["board"], hits["channel"],
+                                     hits["record_id"], float(time_window_ns), fix0, fix1)
+    flat.update({"dt": dt_values, "start_name": start_name, "end_name": end_name})
+    return flat
 
 
-def group_hit_windows(hits: np.ndarray, time_window_ns: float, dt_values: np.ndarray | None = None):
+def group_hit_windows(hits: np.ndarray, time_window_ns: float, dt_values: np.ndarray | None = None,
+                      component_rows: np.ndarray | None = None, component_hits: np.ndarray | None = None,
+                      session=None):
     """Same DataFrame as the reference (ragged per-event arrays in object columns)."""
     import pandas as pd
 
     if isinstance(hits, np.ndarray) and len(hits) == 0:
         return pd.DataFrame(columns=EVENT_COLUMNS)
-    flat = group_hit_windows_flat(hits, time_window_ns, dt_values)
+    flat = group_hit_windows_flat(hits, time_window_ns, dt_values, component_rows, component_hits, session)
     order, es = flat["order"], flat["event_start"]
     cols = {
         "dt": flat["dt"][order].astype(np.int32),

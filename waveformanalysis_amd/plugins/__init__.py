@@ -9,6 +9,7 @@ from .basic_features import HipBasicFeaturesPlugin
 from .filtered_waveforms import HipFilteredWaveformsPlugin
 from .hit_finder import HipHitFinderPlugin
 from .hit_grouped import HipHitGroupedPlugin
+from .hit_merge import HipHitMergeClustersPlugin, HipHitMergedComponentsPlugin, HipHitMergePlugin
 from .s1_s2 import HipS1S2ClassifierPlugin
 from .threshold_hit import HipThresholdHitPlugin
 from .wave_pool_filtered import HipWavePoolFilteredPlugin
@@ -19,9 +20,11 @@ from .width_integral import HipWaveformWidthIntegralPlugin
 def hip_default():
     return [HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
             HipWaveformWidthIntegralPlugin(), HipHitGroupedPlugin(), HipHitFinderPlugin(),
-            HipFilteredWaveformsPlugin(), HipWaveformWidthPlugin(), HipS1S2ClassifierPlugin()]
+            HipFilteredWaveformsPlugin(), HipWaveformWidthPlugin(), HipS1S2ClassifierPlugin(),
+            HipHitMergeClustersPlugin(), HipHitMergePlugin(), HipHitMergedComponentsPlugin()]
 
 
 __all__ = ["HipWavePoolFilteredPlugin", "HipThresholdHitPlugin", "HipBasicFeaturesPlugin",
            "HipWaveformWidthIntegralPlugin", "HipHitGroupedPlugin", "HipHitFinderPlugin", "HipFilteredWaveformsPlugin",
-           "HipWaveformWidthPlugin", "HipS1S2ClassifierPlugin", "hip_default"]
+           "HipWaveformWidthPlugin", "HipS1S2ClassifierPlugin", "HipHitMergeClustersPlugin",
+           "HipHitMergePlugin", "HipHitMergedComponentsPlugin", "hip_default"]

@@ -13,7 +13,8 @@ from . import _common as K
 class HipHitGroupedPlugin(Plugin):
     """Group hits across channels into coincidence events (gap-chained absolute windows).
 
-    Consumes `hit_merged` when that product is available and otherwise the threshold hits
+    Consumes `hit_merged` (+ `hit_merged_components` and `hit_threshold` for merged hits that span
+    records, as the reference does) when that product is registered and otherwise the threshold hits
     directly: with the reference's default `merge_gap_ns = 0` nothing is merged and both give the
     same events.  On several GPUs the rows of all ranks are gathered first (sharding.py).
     """
@@ -30,7 +31,10 @@ class HipHitGroupedPlugin(Plugin):
 
     def resolve_depends_on(self, context: Any, run_id: str | None = None) -> list[str]:
         plugins = getattr(context, "_plugins", {}) or {}
-        return ["hit_merged"] if "hit_merged" in plugins else ["hit_threshold"]
+        data = getattr(context, "_data", {}) or {}
+        if "hit_merged" in plugins or "hit_merged" in data:
+            return ["hit_merged", "hit_merged_components", "hit_threshold"]
+        return ["hit_threshold"]
 
     def compute(self, context: Any, run_id: str, **kwargs) -> Any:
         source = self.resolve_depends_on(context, run_id)[0]
@@ -38,4 +42,11 @@ class HipHitGroupedPlugin(Plugin):
         time_window_ns = float(context.get_config(self, "time_window_ns"))
         explicit_dt = K.resolve_dt_config(context, self, deprecated_keys=("sampling_interval_ns", "dt_ns"))
         dt_values = K.require_dt_array(hits, explicit_dt=explicit_dt, plugin_name=self.provides, data_name=source)
-        return group_hit_windows(hits, time_window_ns=time_window_ns, dt_values=dt_values)
+        component_rows = component_hits = None
+        if source == "hit_merged":
+            component_rows = context.get_data(run_id, "hit_merged_components")
+            component_hits = context.get_data(run_id, "hit_threshold")
+        pool_obj = getattr(context, "wfa_device_pool", None) or K.default_pool()
+        return group_hit_windows(hits, time_window_ns=time_window_ns, dt_values=dt_values,
+                                 component_rows=component_rows, component_hits=component_hits,
+                                 session=pool_obj.session())
