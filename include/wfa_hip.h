@@ -215,6 +215,20 @@ int wfa_group_hit_windows_count(wfa_ctx* ctx, int64_t n_hits, const int64_t* tim
 int wfa_group_hit_windows_fill(wfa_ctx* ctx, int64_t n_hits, int64_t n_events, int64_t* order, int64_t* event_start,
                                int64_t* t_min, int64_t* t_max);
 
+/* ---- records builder (reference: processing/records_builder.py) -------------------------------------------------
+ * K12 global record order: np.lexsort((seq, channel, board, pid, timestamp)) (records_builder.py:115-120), i.e. the
+ * order a k-way merge of sorted parts produces (341-426, 869-945).  order[k] = source row of output row k. */
+int wfa_records_sort(wfa_ctx* ctx, int64_t n_records, const int64_t* timestamp, const int32_t* pid,
+                     const int16_t* board, const int16_t* channel, int64_t* order);
+
+/* K13 pack the wave slices of the records, given in OUTPUT order, into one contiguous pool
+ * (records_builder.py:195-207, 400-409).  src_pool: the concatenated source samples (uint16 bit patterns);
+ * out_offset[r] receives the running sum of max(length, 0).  The packed pool becomes the resident wave_pool of the
+ * context (records must be uploaded again); out_pool, when not NULL, also receives it. */
+int wfa_pool_gather(wfa_ctx* ctx, int64_t n_records, const int64_t* src_offset, const int32_t* length,
+                    const uint16_t* src_pool, int64_t src_samples, int64_t* out_offset, uint16_t* out_pool,
+                    int64_t out_samples);
+
 /* K6 integral-quantile width (reference: waveform_width_integral.py:166-227).
  * out: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B). */
 int wfa_width_integral(wfa_ctx* ctx, int source, double q_low, double q_high, double dt,

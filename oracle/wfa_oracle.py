@@ -739,3 +739,73 @@ def hit_merged_rows(hits: np.ndarray, clusters: list) -> np.ndarray:
                      offset, len(members)))
         offset += len(members)
     return np.array(rows, dtype=HIT_MERGED_DTYPE) if rows else np.zeros(0, dtype=HIT_MERGED_DTYPE)
+
+
+# ------------------------------------------------------------------------------------------------
+# Records builder (processing/records_builder.py), literal restatement
+# ------------------------------------------------------------------------------------------------
+def records_sort_order(records: np.ndarray) -> np.ndarray:
+    """records_builder.py:115-120."""
+    seq = np.arange(len(records), dtype=np.int64)
+    return np.lexsort((seq, records["channel"], records["board"], records["pid"], records["timestamp"]))
+
+
+def build_records_from_st_waveforms(st: np.ndarray, default_dt_ns: int = 1):
+    """records_builder.py:645-794: rows grouped per hardware channel, concatenated, sorted, waves copied one by one."""
+    names = st.dtype.names
+    keys = sorted(set(zip(st["board"].tolist(), st["channel"].tolist())))
+    grouped = np.concatenate([np.flatnonzero((st["board"] == b) & (st["channel"] == c)) for b, c in keys])
+    src = st[grouped]
+    rec = np.zeros(len(src), dtype=RECORDS_DTYPE)
+    for f in ("timestamp", "channel", "board", "baseline"):
+        rec[f] = src[f]
+    rec["baseline_upstream"] = src["baseline_upstream"] if "baseline_upstream" in names else np.nan
+    rec["polarity"] = src["polarity"] if "polarity" in names else "unknown"
+    rec["event_length"] = src["event_length"] if "event_length" in names else src["wave"].shape[1]
+    rec["dt"] = src["dt"] if "dt" in names else default_dt_ns
+    rec["time"] = src["time"] if "time" in names else rec["timestamp"] // 1000
+    order = records_sort_order(rec)
+    rec, src = rec[order], src[order]
+    if "record_id" in names and np.all(src["record_id"] >= 0):
+        rec["record_id"] = src["record_id"]
+    else:
+        rec["record_id"] = np.arange(len(rec))
+    width = src["wave"].shape[1]
+    chunks, cursor = [], 0
+    for i in range(len(rec)):
+        n = min(max(int(rec["event_length"][i]), 0), width)
+        rec["event_length"][i] = n
+        rec["wave_offset"][i] = cursor
+        chunks.append(src["wave"][i][:n].astype(np.uint16))
+        cursor += n
+    pool = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint16)
+    return rec, pool
+
+
+def merge_records_parts(parts):
+    """records_builder.py:869-945: heap k-way merge of sorted (records, wave_pool) parts."""
+    import heapq
+
+    total = sum(len(r) for r, _ in parts)
+    out = np.zeros(total, dtype=RECORDS_DTYPE)
+    heap = []
+    for p, (r, _) in enumerate(parts):
+        if len(r):
+            heapq.heappush(heap, (int(r["timestamp"][0]), int(r["pid"][0]), int(r["board"][0]), int(r["channel"][0]), p, 0))
+    chunks, cursor, k = [], 0, 0
+    while heap:
+        *_, p, row = heapq.heappop(heap)
+        r, pool = parts[p]
+        n = max(int(r["event_length"][row]), 0)
+        off = int(r["wave_offset"][row])
+        chunks.append(np.asarray(pool[off : off + n], dtype=np.uint16))
+        out[k] = r[row]
+        out["wave_offset"][k] = cursor
+        cursor += n
+        k += 1
+        if row + 1 < len(r):
+            heapq.heappush(heap, (int(r["timestamp"][row + 1]), int(r["pid"][row + 1]), int(r["board"][row + 1]),
+                                  int(r["channel"][row + 1]), p, row + 1))
+    if len(np.unique(out["record_id"])) != len(out):
+        out["record_id"] = np.arange(total)
+    return out, (np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint16))

@@ -320,6 +320,55 @@ def merge_case(name, hits, configs, windows=(0, 100, 5000)):
     print(f"{name}: {len(hits)} hits -> (merged, multi, spanning) {sizes} -> {os.path.getsize(path)} B")
 
 
+def sort_case(name, seed):
+    """Reference records builder: build_records_from_st_waveforms (records_builder.py:780-794) on shuffled dense rows
+    with timestamp ties across boards/channels, and merge_records_parts (869-945) on three sorted parts."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.processing.dtypes import create_record_dtype
+    from waveform_analysis.core.processing.records_builder import (
+        RecordsBundle,
+        build_records_from_st_waveforms,
+        merge_records_parts,
+    )
+
+    rng = np.random.default_rng(seed)
+    n, L = 120, 64
+    st = np.zeros(n, dtype=create_record_dtype(L))
+    st["timestamp"] = rng.integers(0, 40, n) * 1000          # many ties
+    st["board"] = rng.integers(0, 3, n)
+    st["channel"] = rng.integers(0, 4, n)
+    st["baseline"] = rng.uniform(7900, 8100, n)
+    st["baseline_upstream"] = np.where(rng.random(n) < 0.5, np.nan, 8000.0)
+    st["polarity"] = rng.choice(["unknown", "negative", "positive"], n)
+    st["dt"] = rng.choice([2, 4], n)
+    st["event_length"] = rng.choice([L, L, L, 40, 0, L + 9], n)   # shorter, empty and over-long rows
+    st["record_id"] = rng.permutation(n)
+    st["wave"] = rng.integers(0, 16384, (n, L)).astype(np.int16)
+    b = build_records_from_st_waveforms(st, default_dt_ns=4)
+    out = {"st_waveforms": st, "records": b.records, "wave_pool": b.wave_pool}
+
+    rec, pool = synth.make_run(150, "v1725", cfg=19)
+    rec["timestamp"] = (rec["timestamp"] // 10**7) * 10**7        # coarse timestamps: ties across parts
+    parts = []
+    for p in range(3):
+        sel = np.flatnonzero(rng.integers(0, 3, len(rec)) == p)
+        r = rec[sel].copy()
+        order = np.lexsort((np.arange(len(r)), r["channel"], r["board"], r["pid"], r["timestamp"]))
+        r = r[order]
+        w = np.concatenate([pool[o : o + n_] for o, n_ in zip(r["wave_offset"], r["event_length"])])
+        r["wave_offset"] = np.concatenate(([0], np.cumsum(r["event_length"][:-1])))
+        r["record_id"] = np.arange(len(r))                          # duplicate ids across parts -> renumbered
+        parts.append(RecordsBundle(r, w.astype(np.uint16)))
+        out[f"part{p}_records"], out[f"part{p}_pool"] = r, parts[-1].wave_pool
+    m = merge_records_parts(parts)
+    out["merged_records"], out["merged_pool"] = m.records, m.wave_pool
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: dense {len(b.records)} rec / {len(b.wave_pool)} samples; merged {len(m.records)} rec / "
+          f"{len(m.wave_pool)} samples -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -462,6 +511,8 @@ def main():
         ctx = Ctx({"wave_source": "records", "threshold": 15.0}, {"records": rec, "wave_pool": pool})
         hits = ThresholdHitPlugin().compute(ctx, "run")
         grouping_case(f"grouping_{preset}", hits, (0, 100, 5000, 2000000))
+
+    sort_case("sort_mixed", 31)
 
     # hit merging: real threshold hits of a 16-channel run, and crafted hits whose chains cross records
     merge_cfgs = [{}, {"merge_gap_ns": 20.0}, {"merge_gap_ns": 400.0, "max_total_width_ns": 1500.0},

@@ -281,6 +281,40 @@ __global__ void k_merge_emit(int64_t n_clusters, const int64_t* __restrict__ off
     out_w[cl] = (float)w;
 }
 
+// ---- records builder: global order + pool packing (records_builder.py:115-120, 164-209, 869-945) --------------
+__global__ void k_record_keys(int64_t n, const int64_t* __restrict__ ts, const int32_t* __restrict__ pid,
+                              const int16_t* __restrict__ board, const int16_t* __restrict__ chan,
+                              uint64_t* __restrict__ k_ts, uint64_t* __restrict__ k_pid, uint64_t* __restrict__ k_bc) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    k_ts[i] = ord_i64(ts[i]);
+    k_pid[i] = (uint64_t)((uint32_t)pid[i] ^ 0x80000000u);
+    k_bc[i] = ((uint64_t)(uint16_t)(board[i] ^ (int16_t)0x8000) << 16) | (uint64_t)(uint16_t)(chan[i] ^ (int16_t)0x8000);
+}
+
+// one workgroup per record; 16-byte moves when source and destination are co-aligned, 2-byte moves otherwise
+__global__ __launch_bounds__(128) void k_pool_gather(int64_t n, const int64_t* __restrict__ src_off,
+                                                     const int64_t* __restrict__ dst_off,
+                                                     const int32_t* __restrict__ length,
+                                                     const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
+    const int64_t r = blockIdx.x;
+    if (r >= n) return;
+    const int64_t so = src_off[r], d0 = dst_off[r];
+    const int len = length[r];
+    if (len <= 0) return;
+    const uint16_t* s = src + so;
+    uint16_t* d = dst + d0;
+    if (((so | d0) & 7) == 0) {
+        const int nv = len >> 3;
+        const uint4* s4 = reinterpret_cast<const uint4*>(s);
+        uint4* d4 = reinterpret_cast<uint4*>(d);
+        for (int i = threadIdx.x; i < nv; i += 128) d4[i] = s4[i];
+        for (int i = (nv << 3) + threadIdx.x; i < len; i += 128) d[i] = s[i];
+    } else {
+        for (int i = threadIdx.x; i < len; i += 128) d[i] = s[i];
+    }
+}
+
 }  // namespace
 }  // namespace wfa
 
@@ -499,6 +533,79 @@ int wfa_hit_merge_emit(wfa_ctx* c, int64_t n, const int64_t* timestamp, const in
     WFA_HIP_CHECK(hipMemcpyAsync(out_end, o_e, m * 4, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipMemcpyAsync(out_width, o_w, m * 4, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_records_sort(wfa_ctx* c, int64_t n, const int64_t* timestamp, const int32_t* pid, const int16_t* board,
+                     const int16_t* channel, int64_t* order) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n < 0) return fail(WFA_E_INVALID, "negative size");
+    if (n == 0) return WFA_OK;
+    if (!timestamp || !pid || !board || !channel || !order) return fail(WFA_E_INVALID, "null argument");
+    int64_t* d_ts;
+    int32_t* d_pid;
+    int16_t *d_b, *d_c;
+    uint64_t *k_ts, *k_pid, *k_bc;
+    if ((rc = upload(c, S_TS, timestamp, n, &d_ts)) || (rc = upload(c, S_DT, pid, n, &d_pid)) ||
+        (rc = upload(c, S_BOARD, board, n, &d_b)) || (rc = upload(c, S_CHAN, channel, n, &d_c)) ||
+        (rc = slot(c, S_K0, n, &k_ts)) || (rc = slot(c, S_K1, n, &k_pid)) || (rc = slot(c, S_K2, n, &k_bc)))
+        return rc;
+    c->ht_n = -1;
+    LaunchTimer t(c);
+    hipLaunchKernelGGL(k_record_keys, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, d_ts, d_pid, d_b, d_c, k_ts, k_pid, k_bc);
+    int64_t* perm = nullptr;
+    const uint64_t* keys[3] = {k_ts, k_pid, k_bc};  // np.lexsort((seq, channel, board, pid, timestamp)); seq = stability
+    if ((rc = lexsort(c, n, keys, 3, &perm))) return rc;
+    if ((rc = t.end("records: global sort order"))) return rc;
+    WFA_HIP_CHECK(hipMemcpyAsync(order, perm, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_pool_gather(wfa_ctx* c, int64_t n, const int64_t* src_offset, const int32_t* length, const uint16_t* src_pool,
+                    int64_t src_samples, int64_t* out_offset, uint16_t* out_pool, int64_t out_samples) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n < 0 || src_samples < 0 || out_samples < 0) return fail(WFA_E_INVALID, "negative size");
+    if (n > 0 && (!src_offset || !length || !out_offset)) return fail(WFA_E_INVALID, "null argument");
+    if (src_samples > 0 && !src_pool) return fail(WFA_E_INVALID, "src_pool is null");
+    // every slice is checked before a kernel indexes with it; offsets of the packed pool are the running sum
+    int64_t cursor = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t len = length[r] > 0 ? length[r] : 0;
+        if (len > 0 && (src_offset[r] < 0 || src_offset[r] + len > src_samples))
+            return fail(WFA_E_INVALID, "record %lld: slice [%lld, %lld) outside the source pool of %lld samples", (long long)r,
+                        (long long)src_offset[r], (long long)(src_offset[r] + len), (long long)src_samples);
+        out_offset[r] = cursor;
+        cursor += len;
+    }
+    if (cursor != out_samples)
+        return fail(WFA_E_INVALID, "lengths add up to %lld samples, caller expects %lld", (long long)cursor, (long long)out_samples);
+    uint16_t* d_src;
+    int64_t *d_so, *d_do;
+    int32_t* d_len;
+    if ((rc = upload(c, S_F0, src_pool, src_samples, &d_src)) || (rc = upload(c, S_K0, src_offset, n, &d_so)) ||
+        (rc = upload(c, S_K1, (const int64_t*)out_offset, n, &d_do)) || (rc = upload(c, S_K2, length, n, &d_len)))
+        return rc;
+    if ((rc = c->pool_u16.ensure((size_t)(out_samples > 0 ? out_samples : 1) * sizeof(uint16_t)))) return rc;
+    {
+        LaunchTimer t(c);
+        if (n > 0)
+            hipLaunchKernelGGL(k_pool_gather, dim3((unsigned)n), dim3(128), 0, c->stream, n, d_so, d_do, d_len, d_src,
+                               c->pool_u16.as<uint16_t>());
+        WFA_HIP_CHECK(hipGetLastError());
+        if ((rc = t.end("k_pool_gather"))) return rc;
+    }
+    if (out_pool && out_samples > 0)
+        WFA_HIP_CHECK(hipMemcpyAsync(out_pool, c->pool_u16.ptr, (size_t)out_samples * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    // the packed pool is now the resident wave_pool
+    c->pool_n = out_samples;
+    c->have_u16 = true;
+    c->have_f32 = false;
+    c->filter_keep = false;
+    c->have_records = false;
     return WFA_OK;
 }
 

@@ -238,6 +238,36 @@ class DeviceSession:
             _ptr(out), _ptr(valid)))
         return out, valid.astype(bool)
 
+    # ---- records builder -----------------------------------------------------------------------------------------
+    def records_sort_order(self, timestamp, pid, board, channel) -> np.ndarray:
+        """np.lexsort((seq, channel, board, pid, timestamp)) on the device (records_builder.py:115-120)."""
+        ts = np.ascontiguousarray(timestamp, dtype=np.int64)
+        cols = [ts, np.ascontiguousarray(pid, dtype=np.int32), np.ascontiguousarray(board, dtype=np.int16),
+                np.ascontiguousarray(channel, dtype=np.int16)]
+        if any(c.shape != ts.shape or c.ndim != 1 for c in cols):
+            raise ValueError("sort columns must be 1-D arrays of one length")
+        order = np.empty(len(ts), dtype=np.int64)
+        _lib.check(self._lib.wfa_records_sort(self._h, len(ts), *[_ptr(c) for c in cols], _ptr(order)))
+        return order
+
+    def pool_gather(self, src_offset, length, src_pool: np.ndarray, download: bool = True):
+        """Pack wave slices (given in output order) into the resident wave_pool -> (out_offset, pool | None)."""
+        so = np.ascontiguousarray(src_offset, dtype=np.int64)
+        ln = np.ascontiguousarray(length, dtype=np.int32)
+        src = np.ascontiguousarray(src_pool)
+        if src.dtype == np.int16:
+            src = src.view(np.uint16)  # _clip_wave_to_uint16: astype(uint16) keeps the bit pattern
+        if src.dtype != np.uint16 or src.ndim != 1:
+            raise ValueError("src_pool must be a flat uint16 / int16 array")
+        total = int(np.maximum(ln, 0).astype(np.int64).sum())
+        out_off = np.empty(len(so), dtype=np.int64)
+        out = np.empty(total, dtype=np.uint16) if download else None
+        _lib.check(self._lib.wfa_pool_gather(self._h, len(so), _ptr(so), _ptr(ln), _ptr(src), src.size, _ptr(out_off),
+                                             _ptr(out), total))
+        self.n_samples = total
+        self.n_records = 0
+        return out_off, out
+
     # ---- hit-table stages (device sort + scans) ------------------------------------------------------------
     @staticmethod
     def _hit_cols(timestamp, position, start, end, dt, board, channel, record_id):

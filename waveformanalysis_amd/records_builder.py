@@ -1,0 +1,155 @@
+"""Records builder: global record order and wave_pool packing on the GPU
+(reference: waveform_analysis/core/processing/records_builder.py:115-120 `_records_sort_order`, 645-794
+`_build_records_from_channels` / `build_records_from_st_waveforms`, 869-945 `merge_records_parts`).
+
+The reference sorts with np.lexsort and then copies every wave slice in a Python loop (or pops a heap per
+record when merging parts).  Here the order is a stable device radix sort (wfa_records_sort) and the packing is
+one gather kernel (wfa_pool_gather) that leaves the packed pool resident on the GPU, so the hit / feature passes
+that follow read it without another upload.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Sequence
+
+import numpy as np
+
+from .dtypes import RECORDS_DTYPE
+
+
+@dataclass
+class RecordsBundle:
+    """records + wave_pool (records_builder.py:35-43)."""
+
+    records: np.ndarray
+    wave_pool: np.ndarray
+
+
+def _session(session):
+    if session is not None:
+        return session
+    from .device import default_pool
+
+    return default_pool().session()
+
+
+def _empty() -> RecordsBundle:
+    return RecordsBundle(np.zeros(0, dtype=RECORDS_DTYPE), np.zeros(0, dtype=np.uint16))
+
+
+def records_sort_order(records: np.ndarray, session=None) -> np.ndarray:
+    """Stable global order by (timestamp, pid, board, channel) (records_builder.py:115-120)."""
+    if len(records) == 0:
+        return np.zeros(0, dtype=np.int64)
+    return _session(session).records_sort_order(records["timestamp"], records["pid"], records["board"], records["channel"])
+
+
+def build_records_from_st_waveforms(st_waveforms: np.ndarray, default_dt_ns: int = 1, session=None) -> RecordsBundle:
+    """records + wave_pool from a dense st_waveforms array, globally sorted (records_builder.py:645-794).
+
+    The reference concatenates the rows per hardware channel and sorts by (timestamp, pid, board, channel, seq);
+    board and channel are sort keys ahead of seq, so that is the stable (timestamp, pid, board, channel) order
+    of the original rows."""
+    if st_waveforms is None or len(st_waveforms) == 0:
+        return _empty()
+    if not isinstance(st_waveforms, np.ndarray) or st_waveforms.dtype.names is None:
+        raise ValueError("st_waveforms must be a structured numpy array")
+    names = st_waveforms.dtype.names
+    if "board" not in names or "channel" not in names:
+        raise ValueError("st_waveforms missing required 'board'/'channel' fields")
+    n = len(st_waveforms)
+    rec = np.zeros(n, dtype=RECORDS_DTYPE)
+    rec["timestamp"] = st_waveforms["timestamp"] if "timestamp" in names else 0
+    rec["pid"] = 0
+    rec["channel"] = st_waveforms["channel"]
+    rec["board"] = st_waveforms["board"].astype(np.int16, copy=False)
+    rec["baseline"] = st_waveforms["baseline"] if "baseline" in names else 0.0
+    rec["baseline_upstream"] = st_waveforms["baseline_upstream"] if "baseline_upstream" in names else np.nan
+    rec["polarity"] = st_waveforms["polarity"] if "polarity" in names else "unknown"
+    if "event_length" in names:
+        lengths = st_waveforms["event_length"].astype(np.int64, copy=False)
+        if lengths.size and lengths.max() > np.iinfo(np.int32).max:
+            raise ValueError("event_length exceeds int32 range")
+        rec["event_length"] = lengths.astype(np.int32, copy=False)
+    elif "wave" in names:
+        rec["event_length"] = np.int32(st_waveforms["wave"].shape[1])
+    rec["dt"] = st_waveforms["dt"].astype(np.int32, copy=False) if "dt" in names else np.int32(default_dt_ns)
+    rec["trigger_type"] = st_waveforms["trigger_type"].astype(np.int16, copy=False) if "trigger_type" in names else 0
+    rec["flags"] = st_waveforms["flags"].astype(np.uint32, copy=False) if "flags" in names else 0
+    rec["time"] = st_waveforms["time"] if "time" in names else rec["timestamp"] // 1000
+    source_record_id = (st_waveforms["record_id"].astype(np.int64, copy=False) if "record_id" in names
+                        else np.full(n, -1, dtype=np.int64))
+
+    sess = _session(session)
+    order = records_sort_order(rec, sess)
+    rec = rec[order]
+    source_record_id = source_record_id[order]
+    rec["record_id"] = source_record_id if np.all(source_record_id >= 0) else np.arange(n, dtype=np.int64)
+    if "wave" not in names:
+        raise ValueError("st_waveforms missing 'wave' field required for wave_pool")
+    wave = st_waveforms["wave"]
+    width = int(wave.shape[-1])
+    rec["event_length"] = np.clip(rec["event_length"].astype(np.int64), 0, width).astype(np.int32)
+    flat = np.ascontiguousarray(wave).reshape(-1)
+    if flat.dtype not in (np.int16, np.uint16):
+        flat = flat.astype(np.uint16)  # _clip_wave_to_uint16
+    out_off, pool = sess.pool_gather(order * width, rec["event_length"], flat)
+    rec["wave_offset"] = out_off
+    return RecordsBundle(records=rec, wave_pool=pool)
+
+
+def _part_is_sorted(records: np.ndarray) -> bool:
+    if len(records) < 2:
+        return True
+    keys = [records[k].astype(np.int64) for k in ("timestamp", "pid", "board", "channel")]
+    later = np.zeros(len(records) - 1, dtype=bool)   # strictly greater decided by an earlier key
+    equal = np.ones(len(records) - 1, dtype=bool)
+    for k in keys:
+        d = np.diff(k)
+        later |= equal & (d > 0)
+        if np.any(equal & ~later & (d < 0)):
+            return False
+        equal &= d == 0
+    return True
+
+
+def merge_records_parts(parts: Sequence[RecordsBundle], session=None) -> RecordsBundle:
+    """Merge sorted parts into one globally sorted bundle (records_builder.py:869-945).
+
+    A k-way heap merge with the tie-break (part index, row index) is the stable sort of the concatenated parts
+    by (timestamp, pid, board, channel) when every part is sorted, which is the documented precondition."""
+    if not parts:
+        return _empty()
+    total_records = sum(len(p.records) for p in parts)
+    if total_records == 0:
+        return _empty()
+    for k, p in enumerate(parts):
+        if not _part_is_sorted(p.records):
+            raise ValueError(f"records part {k} is not sorted by (timestamp, pid, board, channel)")
+    live = [p for p in parts if len(p.records)]
+    records = np.concatenate([p.records for p in live]).astype(RECORDS_DTYPE, copy=False)
+    pool_sizes = np.array([len(p.wave_pool) for p in live], dtype=np.int64)
+    pool_base = np.concatenate(([0], np.cumsum(pool_sizes)[:-1]))
+    src_offset = records["wave_offset"].astype(np.int64) + np.repeat(pool_base, [len(p.records) for p in live])
+    src_pool = np.concatenate([np.asarray(p.wave_pool, dtype=np.uint16) for p in live])
+    sess = _session(session)
+    order = records_sort_order(records, sess)
+    out = records[order]
+    lengths = np.maximum(out["event_length"], 0).astype(np.int32)
+    # the reference slices part.wave_pool[offset:offset+length]: a slice past the part's pool would raise there
+    part_of = np.repeat(np.arange(len(live)), [len(p.records) for p in live])[order]
+    end = out["wave_offset"].astype(np.int64) + lengths
+    bad = (lengths > 0) & ((out["wave_offset"] < 0) | (end > pool_sizes[part_of]))
+    if np.any(bad):
+        i = int(np.flatnonzero(bad)[0])
+        raise ValueError(f"could not broadcast input array: record {i} wave slice outside its part's wave_pool")
+    out_off, pool = sess.pool_gather(src_offset[order], lengths, src_pool)
+    out["wave_offset"] = out_off
+    record_ids = out["record_id"].astype(np.int64, copy=False)
+    if len(np.unique(record_ids)) != len(record_ids):
+        out["record_id"] = np.arange(total_records, dtype=np.int64)
+    return RecordsBundle(records=out, wave_pool=pool)
+
+
+__all__ = ["RecordsBundle", "records_sort_order", "build_records_from_st_waveforms", "merge_records_parts"]
