@@ -192,18 +192,51 @@ __global__ void k_merge_gather(int64_t n, const int64_t* __restrict__ perm, cons
     s0[j] = abs0[i]; s1[j] = abs1[i]; sdt[j] = dt[i]; sg[j] = k_chan[i];
 }
 
-__global__ void k_merge_heads(int64_t n, const uint64_t* __restrict__ sg, int64_t* __restrict__ heads,
-                              unsigned long long* __restrict__ n_heads) {
+// Running maximum of abs_end inside a hardware channel (segmented inclusive max-scan): a hit whose start lies
+// more than merge_gap after EVERY earlier end of its channel certainly opens a new cluster, because the current
+// cluster's end is one of those ends.  Such certain breaks (and channel / dt changes) cut the table into
+// segments that chain independently; the total-width cap, which makes the chain a sequential greedy
+// segmentation, only ever acts inside a segment.
+struct SegMax {
+    double v;
+    int32_t head;  // 1: a channel starts here
+    int32_t pad;
+};
+struct SegMaxOp {
+    __device__ SegMax operator()(const SegMax& a, const SegMax& b) const {
+        SegMax r;
+        r.head = a.head | b.head;
+        r.v = b.head ? b.v : (b.v > a.v ? b.v : a.v);
+        r.pad = 0;
+        return r;
+    }
+};
+__global__ void k_merge_segin(int64_t n, const double* __restrict__ s1, const uint64_t* __restrict__ sg,
+                              SegMax* __restrict__ in) {
     const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
     if (j >= n) return;
-    if (j == 0 || sg[j] != sg[j - 1]) heads[atomicAdd(n_heads, 1ull)] = j;
+    SegMax x;
+    x.v = s1[j];
+    x.head = (j == 0 || sg[j] != sg[j - 1]) ? 1 : 0;
+    x.pad = 0;
+    in[j] = x;
 }
 
-// the chain of hit_merge.py:151-179, one lane per hardware channel (the max-total-width cap makes the chain
-// a genuinely sequential greedy segmentation; channels are independent)
+__global__ void k_merge_heads(int64_t n, const uint64_t* __restrict__ sg, const double* __restrict__ s0,
+                              const int32_t* __restrict__ sdt, const SegMax* __restrict__ run, int do_merge,
+                              double gap_ps, int64_t* __restrict__ heads, unsigned long long* __restrict__ n_heads) {
+    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    const bool certain = j == 0 || sg[j] != sg[j - 1] || !do_merge || sdt[j] != sdt[j - 1] ||
+                         !(s0[j] - run[j - 1].v <= gap_ps);
+    if (certain) heads[atomicAdd(n_heads, 1ull)] = j;
+}
+
+// the chain of hit_merge.py:151-179 over one segment per lane
 __global__ void k_merge_chain(int64_t n, const unsigned long long* __restrict__ n_heads, const int64_t* __restrict__ heads,
                               const double* __restrict__ s0, const double* __restrict__ s1,
-                              const int32_t* __restrict__ sdt, const uint64_t* __restrict__ sg, int do_merge,
+                              const int32_t* __restrict__ sdt, const uint64_t* __restrict__ sg,
+                              const SegMax* __restrict__ run, int do_merge,
                               double gap_ps, double max_width_ps, int64_t* __restrict__ flag) {
     const int64_t g = (int64_t)blockIdx.x * kTB + threadIdx.x;
     if (g >= (int64_t)*n_heads) return;
@@ -213,6 +246,7 @@ __global__ void k_merge_chain(int64_t n, const unsigned long long* __restrict__ 
     int32_t prev_dt = sdt[j];
     flag[j] = 1;
     for (++j; j < n && sg[j] == grp; ++j) {
+        if (!do_merge || sdt[j] != prev_dt || !(s0[j] - run[j - 1].v <= gap_ps)) break;  // the next segment's head
         const double a = s0[j], e = s1[j];
         const double gap = a - c_end;
         const double next_end = e > c_end ? e : c_end;
@@ -243,6 +277,7 @@ __global__ void k_merge_emit(int64_t n_clusters, const int64_t* __restrict__ off
                              HitCols h, const float* __restrict__ height, const float* __restrict__ integral,
                              int64_t* __restrict__ anchor, float* __restrict__ out_h, float* __restrict__ out_int,
                              int32_t* __restrict__ out_s, int32_t* __restrict__ out_e, float* __restrict__ out_w) {
+    __shared__ double s_pw[kPairwiseLevels][kTB];
     const int64_t cl = (int64_t)blockIdx.x * kTB + threadIdx.x;
     if (cl >= n_clusters) return;
     const int64_t a = offset[cl], b = offset[cl + 1];
@@ -272,7 +307,8 @@ __global__ void k_merge_emit(int64_t n_clusters, const int64_t* __restrict__ off
     double w = (double)emax - (double)smin;  // python ints; max(.., 0.0)
     w = w > 0.0 ? w : 0.0;
     if (smin < 0 || emax < 0) w = -1.0;
-    const double total = np_pairwise_sum([&](int q) { return (double)integral[perm[a + q]]; }, 0, (int)(b - a));
+    const double total = np_pairwise_sum([&](int q) { return (double)integral[perm[a + q]]; }, 0, (int)(b - a),
+                                         &s_pw[0][threadIdx.x], kTB);
     anchor[cl] = best;
     out_h[cl] = (float)max_h;
     out_int[cl] = (float)total;
@@ -449,13 +485,22 @@ int wfa_hit_merge_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const i
         if ((rc = lexsort(c, n, keys, 2, &perm))) return rc;
     }
     hipLaunchKernelGGL(k_merge_gather, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, perm, abs0, abs1, h.dt, k_chan, s0, s1, sdt, sg);
-    hipLaunchKernelGGL(k_merge_heads, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, sg, heads, n_heads);
-    // one lane per channel head; n lanes bound the head count
-    hipLaunchKernelGGL(k_merge_chain, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, n_heads, heads, s0, s1, sdt, sg,
-                       merge_gap_ns > 0 ? 1 : 0, merge_gap_ns * 1e3, max_total_width_ns * 1e3, flag);
-    size_t tb = 0;
+    SegMax *seg_in, *seg_run;
+    if ((rc = slot(c, S_OUT1, n, &seg_in)) || (rc = slot(c, S_OUT2, n, &seg_run))) return rc;
+    const int do_merge = merge_gap_ns > 0 ? 1 : 0;
+    const double gap_ps = merge_gap_ns * 1e3;
+    hipLaunchKernelGGL(k_merge_segin, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, s1, sg, seg_in);
+    size_t tb = 0, tb_seg = 0;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, tb_seg, seg_in, seg_run, SegMaxOp(), (int)n, c->stream));
     WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb, flag, incl, (int)n, c->stream));
-    if ((rc = c->ht[S_CUB].ensure(tb))) return rc;
+    if ((rc = c->ht[S_CUB].ensure(tb > tb_seg ? tb : tb_seg))) return rc;
+    tb_seg = c->ht[S_CUB].cap;
+    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(c->ht[S_CUB].ptr, tb_seg, seg_in, seg_run, SegMaxOp(), (int)n, c->stream));
+    hipLaunchKernelGGL(k_merge_heads, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, sg, s0, sdt, seg_run, do_merge, gap_ps,
+                       heads, n_heads);
+    // one lane per segment head; n lanes bound the head count
+    hipLaunchKernelGGL(k_merge_chain, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, n_heads, heads, s0, s1, sdt, sg,
+                       seg_run, do_merge, gap_ps, max_total_width_ns * 1e3, flag);
     tb = c->ht[S_CUB].cap;
     WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->ht[S_CUB].ptr, tb, flag, incl, (int)n, c->stream));
     int64_t n_cl = 0;

@@ -2444,7 +2444,7 @@ __device__ bool peak_passes(const SignalAt<SRC>& S, int peak, const PeakParams& 
 // HIT_DTYPE row of one accepted peak (peak_finding.py:508-563 and _calculate_peak_height 567-614)
 template <int SRC>
 __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64_t r, int peak, double left_ip,
-                               double right_ip, const PeakParams& pp, uint32_t* row, int* err) {
+                               double right_ip, const PeakParams& pp, uint32_t* row, int* err, double* pw_scratch) {
     const int L = S.L;
     int start_idx = (int)rint(left_ip), end_idx = (int)rint(right_ip);  // np.round: half to even
     if (start_idx < 0) start_idx = 0;
@@ -2453,7 +2453,8 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
     if (pp.height_diff) {
         ph = 0.0;
         if (end_idx > start_idx)
-            ph = np_pairwise_sum([&](int q) { return (-S.sig(q + 1)) - (-S.sig(q)); }, start_idx, end_idx - start_idx);
+            ph = np_pairwise_sum([&](int q) { return (-S.sig(q + 1)) - (-S.sig(q)); }, start_idx, end_idx - start_idx,
+                                 pw_scratch, kPeakBlock);
     } else {
         int w0 = start_idx - pp.ext, w1 = end_idx + pp.ext;
         if (w0 < 0) w0 = 0;
@@ -2481,24 +2482,19 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
 
 // Streaming _local_maxima_1d + height + threshold; calls on_peak(position, value) per candidate in order.
 template <int SRC, typename F>
-__device__ void scan_candidates(const SignalAt<SRC>& S, const PeakParams& pp, const F& on_peak) {
+__device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalAt<SRC>& S, const PeakParams& pp,
+                                const F& on_peak) {
     const int n = S.n;
     if (n < 3) return;
+    const int L = S.L;
     bool have = false;
     int c_start = 0;
-    double c_val = 0.0;
-    double x_prev = S.det(0);
-    double s_prev = 0.0;
-    if (S.use_derivative) s_prev = S.sig(1);
-    for (int i = 1; i < n; ++i) {
-        double x;
-        if (S.use_derivative) {  // one new sample per step
-            const double s_next = S.sig(i + 1);
-            x = s_next - s_prev;
-            s_prev = s_next;
-        } else {
-            x = S.sig(i) - 0.0;
-        }
+    double c_val = 0.0, x_prev = 0.0, s_prev = 0.0;
+    // one detection value per step; i is its index.  Samples arrive in aligned 16-byte chunks (8 uint16 or
+    // 2 x 4 float32 per lane and load): a lane walks its own record, so single-sample loads would pull a whole
+    // cache line per 2..4 useful bytes (measured 26 ms per 10^9 samples for the count pass alone).
+    auto step = [&](int i, double x) {
+        if (i == 0) { x_prev = x; return; }
         if (have) {
             if (x < c_val) {
                 const int peak = (c_start + i - 1) / 2;  // midpoint of the plateau
@@ -2516,6 +2512,26 @@ __device__ void scan_candidates(const SignalAt<SRC>& S, const PeakParams& pp, co
             have = true; c_start = i; c_val = x;
         }
         x_prev = x;
+    };
+    const int64_t c_lo = off >> 3, c_hi = (off + L - 1) >> 3;
+    for (int64_t c = c_lo; c <= c_hi; ++c) {
+        double wd[8];
+        float wf[8];
+        load_chunk<SRC>(pool, c, wd, wf);
+        const int kb = (int)(c * 8 - off);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = kb + jj;  // sample index in the record
+            if (k < 0 || k >= L) continue;
+            const float d = wf[jj] - S.b32;
+            const double sk = (double)(S.positive ? d : -d);
+            if (S.use_derivative) {
+                if (k >= 1) step(k - 1, sk - s_prev);
+                s_prev = sk;
+            } else {
+                step(k, sk - 0.0);
+            }
+        }
     }
 }
 
@@ -2527,6 +2543,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecVie
                                                            const int64_t* __restrict__ out_start,
                                                            uint8_t* __restrict__ out, int32_t* __restrict__ cand_pos,
                                                            double* __restrict__ cand_val, int* __restrict__ err) {
+    __shared__ double s_pw[(MODE == 1) ? kPairwiseLevels : 1][kPeakBlock];  // 'diff' height: numpy's pairwise levels
     const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (r >= rec.R) return;
     SignalAt<SRC> S;
@@ -2534,7 +2551,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecVie
     int n_out = 0;
     if (S.L > 0) {
         const int64_t base = (MODE == 1 || MODE == 3) ? out_start[r] : 0;
-        scan_candidates(S, pp, [&](int peak, double val) {
+        scan_candidates(pool, rec.off[r], S, pp, [&](int peak, double val) {
             if (MODE == 2) { ++n_out; return; }
             if (MODE == 3) {
                 cand_pos[base + n_out] = peak;
@@ -2545,7 +2562,8 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecVie
             double l_ip, r_ip;
             if (!peak_passes(S, peak, pp, l_ip, r_ip)) return;
             if (MODE == 1)
-                write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err);
+                write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err,
+                               &s_pw[0][threadIdx.x]);
             ++n_out;
         });
     }
@@ -2590,6 +2608,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks_list(PoolView pool, R
                                                                 int32_t* __restrict__ counts,
                                                                 const int64_t* __restrict__ out_start,
                                                                 uint8_t* __restrict__ out, int* __restrict__ err) {
+    __shared__ double s_pw[FILL ? kPairwiseLevels : 1][kPeakBlock];
     const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (r >= rec.R) return;
     SignalAt<SRC> S;
@@ -2604,7 +2623,8 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks_list(PoolView pool, R
         double l_ip, r_ip;
         if (!peak_passes(S, peak, pp, l_ip, r_ip)) continue;
         if (FILL)
-            write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err);
+            write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err,
+                           &s_pw[0][threadIdx.x]);
         ++n_out;
     }
     if (!FILL) counts[r] = n_out;

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace wfa {
 
 // numpy pairwise_sum (umath/loops_utils.h.src) of f(a) .. f(a+n-1), float64
@@ -25,43 +27,51 @@ __device__ double np_pairwise_leaf(const F& f, int a, int n) {
     return res;
 }
 
+// numpy's recursion for n > 128: split at n2 = n/2 - (n/2) % 8, sum(left) + sum(right).  Iterative post-order walk:
+// the only per-level state that must be kept is the left half's sum, in caller-provided scratch (`sl[level * stride]`,
+// kPairwiseLevels levels: LDS, one column per thread -- register arrays indexed by the level cost 280 VGPRs);
+// a frame's (offset, length) is recomputed from the root by following the path bits.
+constexpr int kPairwiseLevels = 16;  // n <= 128 * 2^16 elements
+
+__device__ __forceinline__ int np_pairwise_split(int n) {
+    const int h = n / 2;
+    return h - h % 8;
+}
+
 template <typename F>
-__device__ double np_pairwise_sum(const F& f, int a0, int n0) {
+__device__ double np_pairwise_sum(const F& f, int a0, int n0, double* sl, int stride) {
     if (n0 <= 128) return np_pairwise_leaf(f, a0, n0);
-    constexpr int kDepth = 28;
-    int sa[kDepth], sn[kDepth], sp[kDepth];
-    double sl[kDepth];
-    int top = 0;
-    sa[0] = a0; sn[0] = n0; sp[0] = 0;
-    double ret = 0.0;
-    while (top >= 0) {
-        const int a = sa[top], n = sn[top];
-        if (n > 128) {  // descend left
-            int n2 = n / 2;
-            n2 -= n2 % 8;
-            sp[top] = 1;
-            ++top;
-            sa[top] = a; sn[top] = n2; sp[top] = 0;
-            continue;
+    uint32_t path = 0;  // bit d set: the walk is in the right half at depth d
+    int depth = 0, a = a0, n = n0;
+    for (;;) {
+        while (n > 128) {  // descend left
+            path &= ~(1u << depth);
+            ++depth;
+            n = np_pairwise_split(n);
         }
-        ret = np_pairwise_leaf(f, a, n);
-        --top;
-        while (top >= 0) {
-            if (sp[top] == 1) {  // left half done: keep it, descend right
-                sl[top] = ret;
-                sp[top] = 2;
-                int n2 = sn[top] / 2;
-                n2 -= n2 % 8;
-                const int pa = sa[top], pn = sn[top];
-                ++top;
-                sa[top] = pa + n2; sn[top] = pn - n2; sp[top] = 0;
+        double ret = np_pairwise_leaf(f, a, n);
+        bool done = true;
+        while (depth > 0) {
+            --depth;
+            int pa = a0, pn = n0;  // frame at `depth`
+            for (int d = 0; d < depth; ++d) {
+                const int n2 = np_pairwise_split(pn);
+                if ((path >> d) & 1u) { pa += n2; pn -= n2; } else { pn = n2; }
+            }
+            if (!((path >> depth) & 1u)) {  // back from the left half: keep its sum, walk the right half
+                sl[depth * stride] = ret;
+                path |= 1u << depth;
+                const int n2 = np_pairwise_split(pn);
+                a = pa + n2;
+                n = pn - n2;
+                ++depth;
+                done = false;
                 break;
             }
-            ret = sl[top] + ret;
-            --top;
+            ret = sl[depth * stride] + ret;
         }
+        if (done) return ret;
     }
-    return ret;
 }
 
 }  // namespace wfa
