@@ -166,6 +166,13 @@ int wfa_basic_features(wfa_ctx* ctx, int source, int64_t height_start, int64_t h
                        int height_has_end, int64_t area_start, int64_t area_end, int area_has_end,
                        const double* fixed_baseline, void* out_rows);
 
+/* K14 legacy threshold crossings on dense rows (reference: processing/event_grouping.py:46-95 `find_hits`):
+ * mask = (baselines[row] - wave) > threshold in float64, one hit per 0 -> 1 transition.  The resident pool is the
+ * row-major wave matrix (as for K10).  fill: event_index / start sample of every hit in row-major order. */
+int wfa_find_hits_count(wfa_ctx* ctx, int source, int64_t n_rows, int32_t row_length, const double* baselines,
+                        double threshold, int64_t* n_hits);
+int wfa_find_hits_fill(wfa_ctx* ctx, int64_t n_hits, int64_t* event_index, int64_t* start_sample);
+
 /* K10 rise/fall/total width per hit on dense waveform rows (reference: cpu/waveform_width.py:205-374).
  * The resident pool is the row-major (n_rows x row_length) wave matrix of st_waveforms (source WFA_SRC_RAW,
  * non-negative int16 ADC codes viewed as uint16) or filtered_waveforms (WFA_SRC_F32).  Per hit: position and

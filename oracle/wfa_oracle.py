@@ -809,3 +809,40 @@ def merge_records_parts(parts):
     if len(np.unique(out["record_id"])) != len(out):
         out["record_id"] = np.arange(total)
     return out, (np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint16))
+
+
+# ------------------------------------------------------------------------------------------------
+# Legacy helpers of processing/event_grouping.py
+# ------------------------------------------------------------------------------------------------
+PEAK_DTYPE = np.dtype(
+    [("time", "i8"), ("area", "f4"), ("height", "f4"), ("width", "f4"), ("channel", "i2"), ("event_index", "i8")]
+)
+
+
+def find_hits_legacy(waves: np.ndarray, baselines: np.ndarray, threshold: float) -> np.ndarray:
+    """event_grouping.py:46-95, row by row: a hit per run of (baseline - wave) > threshold, `time` = its first sample."""
+    rows = []
+    for ev in range(len(waves)):
+        above = (baselines[ev] - waves[ev]) > threshold
+        prev = False
+        for i, m in enumerate(above):
+            if m and not prev:
+                rows.append((i, 0.0, 0.0, 0.0, 0, ev))
+            prev = bool(m)
+    return np.array(rows, dtype=PEAK_DTYPE) if rows else np.zeros(0, dtype=PEAK_DTYPE)
+
+
+def group_multi_channel_hits_literal(ts, ch, area, height, time_window_ns: float):
+    """event_grouping.py:98-283 (single process): stable sort by timestamp, windows from each cluster's first hit,
+    members stably ordered by channel; returns [(t_min, t_max, members as indices into the input)]."""
+    order = np.argsort(ts, kind="stable")
+    ts_s = ts[order]
+    win = time_window_ns * 1e3
+    events, cur, n = [], 0, len(ts_s)
+    while cur < n:
+        nxt = int(np.searchsorted(ts_s, ts_s[cur] + win, side="right"))
+        members = order[cur:nxt]
+        members = members[np.argsort(ch[members], kind="stable")]
+        events.append((int(ts[members[0]]), int(ts[members[-1]]), members))
+        cur = nxt
+    return events

@@ -369,6 +369,58 @@ def sort_case(name, seed):
           f"{len(m.wave_pool)} samples -> {os.path.getsize(path)} B")
 
 
+def legacy_case(name, seed):
+    """Reference legacy helpers: find_hits (event_grouping.py:46-95) on dense int16 / float32 rows and
+    group_multi_channel_hits (98-283) on a hit DataFrame.  The DataFrame has distinct timestamps and no channel
+    twice per window: the reference sorts with unstable kinds, ties would make the fixture CPU-dependent."""
+    if not name.startswith(ONLY):
+        return
+    import pandas as pd
+    from waveform_analysis.core.processing.event_grouping import find_hits, group_multi_channel_hits
+
+    rng = np.random.default_rng(seed)
+    rec, pool = synth.make_run(60, "v1725", cfg=27)
+    waves = pool.reshape(60, 800).astype(np.int16)
+    waves[3, :5] = 0            # run touching the left border
+    waves[4, -7:] = 0           # run touching the right border
+    waves[5, 63:66] = 0         # run across a 64-sample block boundary
+    waves[6, 64] = 0
+    base = rec["baseline"].astype(np.float64)
+    out = {"waves": waves, "baselines": base, "hits_i16": find_hits(waves, base, 12.5)}
+    wf = (waves.astype(np.float32) * np.float32(0.37) + rng.normal(0, 0.2, waves.shape).astype(np.float32))
+    out["waves_f32"] = wf
+    out["baselines_f32"] = (base * 0.37).astype(np.float64)
+    out["hits_f32"] = find_hits(wf, out["baselines_f32"], 4.25)
+
+    rows = []
+    t = 10**9
+    for ev in range(300):
+        t += int(rng.integers(150_000, 5_000_000))                 # > 100 ns = 100 000 ps apart
+        chans = rng.permutation(16)[: int(rng.integers(1, 9))]
+        jit = np.sort(rng.choice(np.arange(1, 90_000), size=len(chans), replace=False))
+        for c, j in zip(chans, jit):
+            rows.append((t + int(j), int(c), float(rng.uniform(5, 900)), float(rng.uniform(10, 200))))
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    df = pd.DataFrame(rows, columns=["timestamp", "channel", "area", "height"])
+    out["df_timestamp"] = df["timestamp"].to_numpy(np.int64)
+    out["df_channel"] = df["channel"].to_numpy(np.int64)
+    out["df_area"] = df["area"].to_numpy(np.float64)
+    out["df_height"] = df["height"].to_numpy(np.float64)
+    for tw in (100, 40):
+        g = group_multi_channel_hits(df, time_window_ns=float(tw), use_numba=False)
+        tag = f"w{tw}"
+        out[f"{tag}_t_min"] = g["t_min"].to_numpy(np.int64)
+        out[f"{tag}_t_max"] = g["t_max"].to_numpy(np.int64)
+        out[f"{tag}_dt_ns"] = g["dt/ns"].to_numpy(np.float64)
+        out[f"{tag}_n_hits"] = g["n_hits"].to_numpy(np.int64)
+        for col in ("channels", "areas", "heights", "timestamps"):
+            out[f"{tag}_{col}"] = np.concatenate(list(g[col]))
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: hits {len(out['hits_i16'])} / {len(out['hits_f32'])}, events {len(out['w100_t_min'])} / "
+          f"{len(out['w40_t_min'])} -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -513,6 +565,7 @@ def main():
         grouping_case(f"grouping_{preset}", hits, (0, 100, 5000, 2000000))
 
     sort_case("sort_mixed", 31)
+    legacy_case("legacy_helpers", 41)
 
     # hit merging: real threshold hits of a 16-channel run, and crafted hits whose chains cross records
     merge_cfgs = [{}, {"merge_gap_ns": 20.0}, {"merge_gap_ns": 400.0, "max_total_width_ns": 1500.0},

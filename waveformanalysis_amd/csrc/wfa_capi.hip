@@ -344,7 +344,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
                       &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
-                        &c->peak_cand_state, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.mfma, &c->sg.tab,
+                        &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.mfma, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
@@ -683,7 +683,6 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int use_derivative, double heig
     const RecView rv = rec_view(c);
     int* err = reinterpret_cast<int*>(c->cursor.ptr);
     int32_t* counts = c->rec_nhits.as<int32_t>();
-    int64_t* out_start = c->rec_out_start.as<int64_t>();
     auto scan_total = [&](int64_t* starts, int64_t* total) -> int {
         WFA_HIP_CHECK(launch_scan(c->stream, counts, R, c->scan_blocks.as<int64_t>(), starts));
         WFA_HIP_CHECK(hipMemcpyAsync(total, c->scan_blocks.as<int64_t>() + nb, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
@@ -691,20 +690,7 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int use_derivative, double heig
         return WFA_OK;
     };
     int64_t total = 0;
-    if (distance <= 2) {
-        // local maxima are at least 2 samples apart: scipy's distance step keeps all of them
-        {
-            LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 0, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr, err));
-            if ((rc = t.end("k_find_peaks<count>"))) return rc;
-        }
-        if ((rc = scan_total(out_start, &total))) return rc;
-        if ((rc = c->peak_out.ensure((size_t)total * 48))) return rc;
-        LaunchTimer t(c);
-        WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 1, pv, rv, pp, nullptr, out_start, c->peak_out.as<uint8_t>(),
-                                        nullptr, nullptr, err));
-        if ((rc = t.end("k_find_peaks<fill>"))) return rc;
-    } else {
+    {
         if ((rc = c->rec_tmp_start.ensure(R * sizeof(int64_t)))) return rc;
         if ((rc = c->peak_cand_n.ensure(R * sizeof(int32_t)))) return rc;
         int64_t* cand_start = c->rec_tmp_start.as<int64_t>();
@@ -712,31 +698,51 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int use_derivative, double heig
         int64_t n_cand = 0;
         {
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 2, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr, err));
-            if ((rc = t.end("k_find_peaks<candidates>"))) return rc;
+            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, false, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr));
+            if ((rc = t.end("k_find_peaks<count candidates>"))) return rc;
         }
         if ((rc = scan_total(cand_start, &n_cand))) return rc;
-        WFA_HIP_CHECK(hipMemcpyAsync(cand_n, counts, R * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-        if ((rc = c->peak_cand_pos.ensure((size_t)n_cand * sizeof(int32_t)))) return rc;
-        if ((rc = c->peak_cand_val.ensure((size_t)n_cand * sizeof(double)))) return rc;
-        if ((rc = c->peak_cand_state.ensure((size_t)n_cand))) return rc;
+        const size_t nc = (size_t)(n_cand > 0 ? n_cand : 1);
+        if ((rc = c->peak_cand_pos.ensure(nc * sizeof(int32_t)))) return rc;
+        if ((rc = c->peak_cand_val.ensure(nc * sizeof(double)))) return rc;
+        if ((rc = c->peak_cand_rec.ensure(nc * sizeof(int64_t)))) return rc;
+        if ((rc = c->peak_cand_state.ensure(nc))) return rc;
+        if ((rc = c->peak_accept.ensure(nc * sizeof(int32_t)))) return rc;
+        if ((rc = c->peak_ips.ensure(nc * 2 * sizeof(double)))) return rc;
+        if ((rc = c->peak_row_start.ensure(nc * sizeof(int64_t)))) return rc;
         int32_t* cpos = c->peak_cand_pos.as<int32_t>();
         double* cval = c->peak_cand_val.as<double>();
-        uint8_t* cstate = c->peak_cand_state.as<uint8_t>();
+        int64_t* crec = c->peak_cand_rec.as<int64_t>();
+        uint8_t* cstate = distance > 2 ? c->peak_cand_state.as<uint8_t>() : nullptr;
+        int32_t* accept = c->peak_accept.as<int32_t>();
         {
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, 3, pv, rv, pp, nullptr, cand_start, nullptr, cpos, cval, err));
-            WFA_HIP_CHECK(launch_peak_select(c->stream, R, cand_n, cand_start, cpos, cval, cstate, distance));
-            WFA_HIP_CHECK(launch_find_peaks_list(c->stream, source, false, pv, rv, pp, cand_n, cand_start, cpos, cstate,
-                                                 counts, nullptr, nullptr, err));
-            if ((rc = t.end("k_find_peaks<candidates+select+count>"))) return rc;
+            WFA_HIP_CHECK(launch_find_peaks(c->stream, source, true, pv, rv, pp, nullptr, cand_start, cpos, cval, crec));
+            if ((rc = t.end("k_find_peaks<fill candidates>"))) return rc;
         }
-        if ((rc = scan_total(out_start, &total))) return rc;
+        if (distance > 2) {  // local maxima are at least 2 samples apart: scipy's distance step keeps all of them otherwise
+            WFA_HIP_CHECK(hipMemcpyAsync(cand_n, counts, R * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_peak_select(c->stream, R, cand_n, cand_start, cpos, cval, cstate, distance));
+            if ((rc = t.end("k_peak_select"))) return rc;
+        }
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_peak_eval(c->stream, source, pv, rv, pp, n_cand, crec, cpos, cstate, accept, c->peak_ips.as<double>()));
+            if ((rc = t.end("k_peak_eval"))) return rc;
+        }
+        if (n_cand > 0) {
+            const int64_t nbc = scan_blocks_for(n_cand);
+            if ((rc = c->scan_blocks.ensure((nbc + 1) * sizeof(int64_t)))) return rc;
+            WFA_HIP_CHECK(launch_scan(c->stream, accept, n_cand, c->scan_blocks.as<int64_t>(), c->peak_row_start.as<int64_t>()));
+            WFA_HIP_CHECK(hipMemcpyAsync(&total, c->scan_blocks.as<int64_t>() + nbc, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
         if ((rc = c->peak_out.ensure((size_t)total * 48))) return rc;
         LaunchTimer t(c);
-        WFA_HIP_CHECK(launch_find_peaks_list(c->stream, source, true, pv, rv, pp, cand_n, cand_start, cpos, cstate, nullptr,
-                                             out_start, c->peak_out.as<uint8_t>(), err));
-        if ((rc = t.end("k_find_peaks_list<fill>"))) return rc;
+        WFA_HIP_CHECK(launch_peak_rows(c->stream, source, pv, rv, pp, n_cand, crec, cpos, accept, c->peak_row_start.as<int64_t>(),
+                                       c->peak_ips.as<double>(), c->peak_out.as<uint8_t>(), err));
+        if ((rc = t.end("k_peak_rows"))) return rc;
     }
     int flag = 0;
     WFA_HIP_CHECK(hipMemcpyAsync(&flag, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -786,6 +792,61 @@ int wfa_basic_features(wfa_ctx* c, int source, int64_t h0, int64_t h1, int h_has
         if ((rc = t.end("k_basic_features"))) return rc;
     }
     WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 36, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_find_hits_count(wfa_ctx* c, int source, int64_t n_rows, int32_t row_length, const double* baselines,
+                        double threshold, int64_t* n_hits) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32)
+        return fail(WFA_E_INVALID, "find_hits reads dense rows: source must be WFA_SRC_RAW or WFA_SRC_F32");
+    if (source == WFA_SRC_RAW ? !c->have_u16 : !c->have_f32) return fail(WFA_E_STATE, "no wave matrix uploaded for this source");
+    if (n_rows < 0 || row_length < 0 || !n_hits) return fail(WFA_E_INVALID, "bad arguments");
+    if (n_rows * (int64_t)row_length > c->pool_n)
+        return fail(WFA_E_INVALID, "wave matrix %lld x %d exceeds the resident pool (%lld samples)", (long long)n_rows,
+                    row_length, (long long)c->pool_n);
+    c->n_legacy = -1;
+    if (n_rows == 0 || row_length == 0) { c->n_legacy = 0; *n_hits = 0; return WFA_OK; }
+    if (!baselines) return fail(WFA_E_INVALID, "baselines is null");
+    if ((rc = c->fixed_bl.ensure((size_t)n_rows * sizeof(double)))) return rc;
+    WFA_HIP_CHECK(hipMemcpyAsync(c->fixed_bl.ptr, baselines, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = c->rec_nhits.ensure(n_rows * sizeof(int32_t)))) return rc;
+    if ((rc = c->rec_out_start.ensure(n_rows * sizeof(int64_t)))) return rc;
+    const int64_t nb = scan_blocks_for(n_rows);
+    if ((rc = c->scan_blocks.ensure((nb + 1) * sizeof(int64_t)))) return rc;
+    const PoolView pv = pool_view(c);
+    LaunchTimer t(c);
+    WFA_HIP_CHECK(launch_find_hits_legacy(c->stream, source, false, pv, n_rows, row_length, c->fixed_bl.as<double>(), threshold,
+                                          c->rec_nhits.as<int32_t>(), nullptr, nullptr, nullptr));
+    WFA_HIP_CHECK(launch_scan(c->stream, c->rec_nhits.as<int32_t>(), n_rows, c->scan_blocks.as<int64_t>(),
+                              c->rec_out_start.as<int64_t>()));
+    int64_t total = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&total, c->scan_blocks.as<int64_t>() + nb, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if ((rc = c->peak_row_start.ensure((size_t)(total > 0 ? total : 1) * sizeof(int64_t)))) return rc;
+    if ((rc = c->peak_ips.ensure((size_t)(total > 0 ? total : 1) * sizeof(int64_t)))) return rc;
+    WFA_HIP_CHECK(launch_find_hits_legacy(c->stream, source, true, pv, n_rows, row_length, c->fixed_bl.as<double>(), threshold,
+                                          nullptr, c->rec_out_start.as<int64_t>(), c->peak_row_start.as<int64_t>(),
+                                          c->peak_ips.as<int64_t>()));
+    if ((rc = t.end("k_find_hits_legacy (count + scan + fill)"))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->n_legacy = total;
+    *n_hits = total;
+    return WFA_OK;
+}
+
+int wfa_find_hits_fill(wfa_ctx* c, int64_t n_hits, int64_t* event_index, int64_t* start_sample) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (c->n_legacy < 0) return fail(WFA_E_STATE, "no find_hits pass has been run");
+    if (n_hits != c->n_legacy)
+        return fail(WFA_E_INVALID, "caller expects %lld hits, the pass produced %lld", (long long)n_hits, (long long)c->n_legacy);
+    if (n_hits == 0) return WFA_OK;
+    if (!event_index || !start_sample) return fail(WFA_E_INVALID, "null output");
+    WFA_HIP_CHECK(hipMemcpyAsync(event_index, c->peak_row_start.ptr, (size_t)n_hits * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(start_sample, c->peak_ips.ptr, (size_t)n_hits * 8, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return WFA_OK;
 }

@@ -105,7 +105,9 @@ struct wfa_ctx {
     wfa::DevBuf out_rows;  // per-record feature rows
     wfa::DevBuf peak_out;  // HIT_DTYPE rows of the last find_peaks pass
     int64_t n_peaks = -1;
-    wfa::DevBuf peak_cand_n, peak_cand_pos, peak_cand_val, peak_cand_state;  // distance > 2: candidate lists
+    int64_t n_legacy = -1;  // hits of the last wfa_find_hits_count pass
+    wfa::DevBuf peak_cand_n, peak_cand_pos, peak_cand_val, peak_cand_state;  // candidate lists of find_peaks
+    wfa::DevBuf peak_cand_rec, peak_accept, peak_ips, peak_row_start;
     wfa::DevBuf wh_pos, wh_row, wh_valid;  // per-hit inputs of k_waveform_width
     // hit-table stages (wfa_hits.hip): scratch slots and the state of the last count pass
     wfa::DevBuf ht[40];

@@ -222,25 +222,17 @@ __global__ void k_merge_segin(int64_t n, const double* __restrict__ s1, const ui
     in[j] = x;
 }
 
-__global__ void k_merge_heads(int64_t n, const uint64_t* __restrict__ sg, const double* __restrict__ s0,
-                              const int32_t* __restrict__ sdt, const SegMax* __restrict__ run, int do_merge,
-                              double gap_ps, int64_t* __restrict__ heads, unsigned long long* __restrict__ n_heads) {
-    const int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
-    if (j >= n) return;
-    const bool certain = j == 0 || sg[j] != sg[j - 1] || !do_merge || sdt[j] != sdt[j - 1] ||
-                         !(s0[j] - run[j - 1].v <= gap_ps);
-    if (certain) heads[atomicAdd(n_heads, 1ull)] = j;
-}
-
-// the chain of hit_merge.py:151-179 over one segment per lane
-__global__ void k_merge_chain(int64_t n, const unsigned long long* __restrict__ n_heads, const int64_t* __restrict__ heads,
-                              const double* __restrict__ s0, const double* __restrict__ s1,
+// the chain of hit_merge.py:151-179 over one segment per lane: every lane looks at its own sorted position and
+// walks only if a segment starts there (no list of heads: a single atomic counter serialises at ~90 appends / us)
+__global__ void k_merge_chain(int64_t n, const double* __restrict__ s0, const double* __restrict__ s1,
                               const int32_t* __restrict__ sdt, const uint64_t* __restrict__ sg,
                               const SegMax* __restrict__ run, int do_merge,
                               double gap_ps, double max_width_ps, int64_t* __restrict__ flag) {
-    const int64_t g = (int64_t)blockIdx.x * kTB + threadIdx.x;
-    if (g >= (int64_t)*n_heads) return;
-    int64_t j = heads[g];
+    int64_t j = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (j >= n) return;
+    const bool head = j == 0 || sg[j] != sg[j - 1] || !do_merge || sdt[j] != sdt[j - 1] ||
+                      !(s0[j] - run[j - 1].v <= gap_ps);
+    if (!head) return;
     const uint64_t grp = sg[j];
     double c_start = s0[j], c_end = s1[j];
     int32_t prev_dt = sdt[j];
@@ -467,15 +459,13 @@ int wfa_hit_merge_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const i
     double *abs0, *abs1, *s0, *s1;
     uint64_t *k_abs, *k_chan, *sg;
     int32_t* sdt;
-    int64_t *flag, *incl, *heads;
-    unsigned long long* n_heads;
+    int64_t *flag, *incl;
     if ((rc = slot(c, S_ABS0, n, &abs0)) || (rc = slot(c, S_ABS1, n, &abs1)) || (rc = slot(c, S_K0, n, &k_abs)) ||
         (rc = slot(c, S_K4, n, &k_chan)) || (rc = slot(c, S_F0, n, &s0)) || (rc = slot(c, S_F1, n, &s1)) ||
         (rc = slot(c, S_K1, n, &sdt)) || (rc = slot(c, S_SG, n, &sg)) || (rc = slot(c, S_FLAG, n, &flag)) ||
-        (rc = slot(c, S_ID, n, &incl)) || (rc = slot(c, S_K2, n, &heads)) || (rc = slot(c, S_CNT, 1, &n_heads)))
+        (rc = slot(c, S_ID, n, &incl)))
         return rc;
     LaunchTimer t(c);
-    WFA_HIP_CHECK(hipMemsetAsync(n_heads, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_hit_prep, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, h, (const double*)nullptr,
                        (const double*)nullptr, abs0, abs1, k_abs, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr, k_chan);
     int64_t* perm = nullptr;
@@ -496,11 +486,8 @@ int wfa_hit_merge_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const i
     if ((rc = c->ht[S_CUB].ensure(tb > tb_seg ? tb : tb_seg))) return rc;
     tb_seg = c->ht[S_CUB].cap;
     WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(c->ht[S_CUB].ptr, tb_seg, seg_in, seg_run, SegMaxOp(), (int)n, c->stream));
-    hipLaunchKernelGGL(k_merge_heads, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, sg, s0, sdt, seg_run, do_merge, gap_ps,
-                       heads, n_heads);
-    // one lane per segment head; n lanes bound the head count
-    hipLaunchKernelGGL(k_merge_chain, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, n_heads, heads, s0, s1, sdt, sg,
-                       seg_run, do_merge, gap_ps, max_total_width_ns * 1e3, flag);
+    hipLaunchKernelGGL(k_merge_chain, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, s0, s1, sdt, sg, seg_run, do_merge,
+                       gap_ps, max_total_width_ns * 1e3, flag);
     tb = c->ht[S_CUB].cap;
     WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->ht[S_CUB].ptr, tb, flag, incl, (int)n, c->stream));
     int64_t n_cl = 0;

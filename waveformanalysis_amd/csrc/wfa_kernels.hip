@@ -2204,6 +2204,45 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
 }
 
 // =============================================================================================
+// K14: legacy threshold crossings on dense rows  (event_grouping.py:46-95 `find_hits`)
+// =============================================================================================
+// mask = (baseline - wave) > threshold in float64; one row per wave; a hit = a 0 -> 1 transition of the mask.
+// Output (event_index, start sample) in row-major order, which is np.where's order.
+template <int SRC, bool FILL>
+__global__ __launch_bounds__(kBlock) void k_find_hits_legacy(PoolView pool, int64_t n_rows, int32_t L,
+                                                            const double* __restrict__ baselines, double threshold,
+                                                            int32_t* __restrict__ counts,
+                                                            const int64_t* __restrict__ out_start,
+                                                            int64_t* __restrict__ out_event, int64_t* __restrict__ out_time) {
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (row >= n_rows) return;
+    const double b = baselines[row];
+    const uint16_t* xu = pool.u16 ? pool.u16 + row * L : nullptr;
+    const float* xf = pool.f32 ? pool.f32 + row * L : nullptr;
+    int64_t n_out = FILL ? out_start[row] : 0;
+    uint64_t prev_last = 0;  // mask bit of the sample before this 64-sample block
+    for (int base = 0; base < L; base += kWave) {
+        const int i = base + lane;
+        bool m = false;
+        if (i < L) {
+            const double w = SRC == WFA_SRC_RAW ? (double)xu[i] : (double)xf[i];
+            m = (b - w) > threshold;
+        }
+        const uint64_t bits = __ballot(m);
+        const uint64_t starts = bits & ~((bits << 1) | prev_last);
+        if (FILL && ((starts >> lane) & 1ull)) {
+            const int64_t k = n_out + __popcll(starts & ((1ull << lane) - 1ull));
+            out_event[k] = row;
+            out_time[k] = i;
+        }
+        n_out += __popcll(starts);
+        prev_last = bits >> 63;
+    }
+    if (!FILL && lane == 0) counts[row] = (int32_t)n_out;
+}
+
+// =============================================================================================
 // K10: rise / fall / total width per hit on dense rows  (waveform_width.py:205-374)
 // =============================================================================================
 // One lane per hit.  T = double for int16 rows (numpy promotes int16 - float64 mean to float64), float for
@@ -2365,11 +2404,10 @@ __global__ __launch_bounds__(128) void k_waveform_width(PoolView pool, int64_t n
 //   det = diff(signal)  (use_derivative)  or  signal,   signal = -rv.signals(id) as float64 of float32
 // in scipy's order: local maxima with plateaus (_local_maxima_1d, streamed) -> height -> threshold ->
 // distance (_select_by_peak_distance) -> prominence (_peak_prominences) -> width at half prominence
-// (_peak_widths, interpolated intersection points).  Every pass runs twice (count, then fill at the
-// scanned offsets) so rows come out in (record, position) order without a gather and nothing is capped.
-//   distance <= 2 (the default; a no-op for local maxima): candidates are consumed as they stream by.
-//   distance  > 2: candidates (position, value) go to a global list, k_peak_select marks the survivors in
-//                  scipy's priority order, then the later stages walk the list.
+// (_peak_widths, interpolated intersection points).  Passes: candidates per record (count, scan, fill),
+// k_peak_select (distance > 2 only; a no-op for local maxima otherwise), then one lane per candidate for the
+// prominence / width walks and, after a scan of the accept flags, for the rows: (record, position) order without a
+// gather, nothing capped.
 constexpr int kPeakBlock = 128;
 constexpr int kPeakErrEmptyWindow = 2;
 
@@ -2535,39 +2573,33 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
     }
 }
 
-// MODE 0/1: count / fill final rows straight from the stream (distance <= 2)
-// MODE 2/3: count / fill the candidate list (distance > 2)
-template <int SRC, int MODE>
+// Candidate pass: FILL = false counts the local maxima that pass `height` / `threshold` per record, FILL = true
+// writes (position, value, record) at the scanned offsets.  Everything after it runs one lane per CANDIDATE:
+// the prominence / width walks are data-dependent pointer walks, and inside the per-record scan they ran with the
+// other 63 lanes of the wave idle (36 ms per 10^9 samples against 2 ms for the scan itself).
+template <int SRC, bool FILL>
 __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecView rec, PeakParams pp,
                                                            int32_t* __restrict__ counts,
                                                            const int64_t* __restrict__ out_start,
-                                                           uint8_t* __restrict__ out, int32_t* __restrict__ cand_pos,
-                                                           double* __restrict__ cand_val, int* __restrict__ err) {
-    __shared__ double s_pw[(MODE == 1) ? kPairwiseLevels : 1][kPeakBlock];  // 'diff' height: numpy's pairwise levels
+                                                           int32_t* __restrict__ cand_pos, double* __restrict__ cand_val,
+                                                           int64_t* __restrict__ cand_rec) {
     const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (r >= rec.R) return;
     SignalAt<SRC> S;
     S.bind(pool, rec, r, pp.use_derivative);
     int n_out = 0;
     if (S.L > 0) {
-        const int64_t base = (MODE == 1 || MODE == 3) ? out_start[r] : 0;
+        const int64_t base = FILL ? out_start[r] : 0;
         scan_candidates(pool, rec.off[r], S, pp, [&](int peak, double val) {
-            if (MODE == 2) { ++n_out; return; }
-            if (MODE == 3) {
+            if (FILL) {
                 cand_pos[base + n_out] = peak;
                 cand_val[base + n_out] = val;
-                ++n_out;
-                return;
+                cand_rec[base + n_out] = r;
             }
-            double l_ip, r_ip;
-            if (!peak_passes(S, peak, pp, l_ip, r_ip)) return;
-            if (MODE == 1)
-                write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err,
-                               &s_pw[0][threadIdx.x]);
             ++n_out;
         });
     }
-    if (MODE == 0 || MODE == 2) counts[r] = n_out;
+    if (!FILL) counts[r] = n_out;
 }
 
 // _select_by_peak_distance on the candidate list of each record: visit candidates by descending value (ties: the
@@ -2599,35 +2631,45 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_select(int64_t R, const int
     }
 }
 
-template <int SRC, bool FILL>
-__global__ __launch_bounds__(kPeakBlock) void k_find_peaks_list(PoolView pool, RecView rec, PeakParams pp,
-                                                                const int32_t* __restrict__ cand_count,
-                                                                const int64_t* __restrict__ cand_start,
-                                                                const int32_t* __restrict__ cand_pos,
-                                                                const uint8_t* __restrict__ state,
-                                                                int32_t* __restrict__ counts,
-                                                                const int64_t* __restrict__ out_start,
-                                                                uint8_t* __restrict__ out, int* __restrict__ err) {
-    __shared__ double s_pw[FILL ? kPairwiseLevels : 1][kPeakBlock];
-    const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
-    if (r >= rec.R) return;
+// one lane per candidate: prominence + width -> accept flag and the two interpolated intersection points
+template <int SRC>
+__global__ __launch_bounds__(kPeakBlock) void k_peak_eval(PoolView pool, RecView rec, PeakParams pp, int64_t n_cand,
+                                                          const int64_t* __restrict__ cand_rec,
+                                                          const int32_t* __restrict__ cand_pos,
+                                                          const uint8_t* __restrict__ state,
+                                                          int32_t* __restrict__ accept, double* __restrict__ ips) {
+    const int64_t k = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    if (k >= n_cand) return;
+    int ok = 0;
+    double l_ip = 0.0, r_ip = 0.0;
+    if (!state || state[k]) {
+        SignalAt<SRC> S;
+        S.bind(pool, rec, cand_rec[k], pp.use_derivative);
+        ok = peak_passes(S, cand_pos[k], pp, l_ip, r_ip) ? 1 : 0;
+    }
+    accept[k] = ok;
+    ips[2 * k] = l_ip;
+    ips[2 * k + 1] = r_ip;
+}
+
+// one lane per candidate: accepted ones write their HIT_DTYPE row at the scanned offset (candidate order is
+// (record, position) order, so the rows are too)
+template <int SRC>
+__global__ __launch_bounds__(kPeakBlock) void k_peak_rows(PoolView pool, RecView rec, PeakParams pp, int64_t n_cand,
+                                                          const int64_t* __restrict__ cand_rec,
+                                                          const int32_t* __restrict__ cand_pos,
+                                                          const int32_t* __restrict__ accept,
+                                                          const int64_t* __restrict__ row_start,
+                                                          const double* __restrict__ ips, uint8_t* __restrict__ out,
+                                                          int* __restrict__ err) {
+    __shared__ double s_pw[kPairwiseLevels][kPeakBlock];  // 'diff' height: numpy's pairwise levels
+    const int64_t k = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    if (k >= n_cand || !accept[k]) return;
+    const int64_t r = cand_rec[k];
     SignalAt<SRC> S;
     S.bind(pool, rec, r, pp.use_derivative);
-    const int K = cand_count[r];
-    const int64_t b = cand_start[r];
-    const int64_t base = FILL ? out_start[r] : 0;
-    int n_out = 0;
-    for (int k = 0; k < K; ++k) {
-        if (!state[b + k]) continue;
-        const int peak = cand_pos[b + k];
-        double l_ip, r_ip;
-        if (!peak_passes(S, peak, pp, l_ip, r_ip)) continue;
-        if (FILL)
-            write_peak_row(S, rec, r, peak, l_ip, r_ip, pp, reinterpret_cast<uint32_t*>(out + (base + n_out) * 48), err,
-                           &s_pw[0][threadIdx.x]);
-        ++n_out;
-    }
-    if (!FILL) counts[r] = n_out;
+    write_peak_row(S, rec, r, cand_pos[k], ips[2 * k], ips[2 * k + 1], pp,
+                   reinterpret_cast<uint32_t*>(out + row_start[k] * 48), err, &s_pw[0][threadIdx.x]);
 }
 
 // =============================================================================================
@@ -2829,6 +2871,20 @@ hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecVie
     return hipGetLastError();
 }
 
+hipError_t launch_find_hits_legacy(hipStream_t st, int source, bool fill, const PoolView& pool, int64_t n_rows, int32_t L,
+                                   const double* baselines, double threshold, int32_t* counts, const int64_t* out_start,
+                                   int64_t* out_event, int64_t* out_time) {
+    if (n_rows == 0) return hipSuccess;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+#define WFA_FH(SRC, F) \
+    hipLaunchKernelGGL((k_find_hits_legacy<SRC, F>), dim3(grid), dim3(kBlock), 0, st, pool, n_rows, L, baselines, threshold, counts, out_start, out_event, out_time)
+    if (source == WFA_SRC_RAW) { if (fill) WFA_FH(WFA_SRC_RAW, true); else WFA_FH(WFA_SRC_RAW, false); }
+    else { if (fill) WFA_FH(WFA_SRC_F32, true); else WFA_FH(WFA_SRC_F32, false); }
+#undef WFA_FH
+    return hipGetLastError();
+}
+
 hipError_t launch_waveform_width(hipStream_t st, int source, const PoolView& pool, int64_t n_hits,
                                  const int64_t* position, const int64_t* row_index, int64_t n_rows, int32_t L,
                                  double rise_low, double rise_high, double fall_high, double fall_low,
@@ -2845,23 +2901,16 @@ hipError_t launch_waveform_width(hipStream_t st, int source, const PoolView& poo
     return hipGetLastError();
 }
 
-hipError_t launch_find_peaks(hipStream_t st, int source, int mode, const PoolView& pool, const RecView& rec,
-                             const PeakParams& pp, int32_t* counts, const int64_t* out_start, uint8_t* out,
-                             int32_t* cand_pos, double* cand_val, int* err) {
+hipError_t launch_find_peaks(hipStream_t st, int source, bool fill, const PoolView& pool, const RecView& rec,
+                             const PeakParams& pp, int32_t* counts, const int64_t* out_start, int32_t* cand_pos,
+                             double* cand_val, int64_t* cand_rec) {
     if (rec.R == 0) return hipSuccess;
     if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((rec.R + kPeakBlock - 1) / kPeakBlock);
-#define WFA_PK(SRC, M) \
-    hipLaunchKernelGGL((k_find_peaks<SRC, M>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, counts, out_start, out, cand_pos, cand_val, err)
-#define WFA_PK_SRC(M) do { if (source == WFA_SRC_RAW) WFA_PK(WFA_SRC_RAW, M); else WFA_PK(WFA_SRC_F32, M); } while (0)
-    switch (mode) {
-        case 0: WFA_PK_SRC(0); break;
-        case 1: WFA_PK_SRC(1); break;
-        case 2: WFA_PK_SRC(2); break;
-        case 3: WFA_PK_SRC(3); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef WFA_PK_SRC
+#define WFA_PK(SRC, F) \
+    hipLaunchKernelGGL((k_find_peaks<SRC, F>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, counts, out_start, cand_pos, cand_val, cand_rec)
+    if (source == WFA_SRC_RAW) { if (fill) WFA_PK(WFA_SRC_RAW, true); else WFA_PK(WFA_SRC_RAW, false); }
+    else { if (fill) WFA_PK(WFA_SRC_F32, true); else WFA_PK(WFA_SRC_F32, false); }
 #undef WFA_PK
     return hipGetLastError();
 }
@@ -2875,18 +2924,29 @@ hipError_t launch_peak_select(hipStream_t st, int64_t R, const int32_t* counts, 
     return hipGetLastError();
 }
 
-hipError_t launch_find_peaks_list(hipStream_t st, int source, bool fill, const PoolView& pool, const RecView& rec,
-                                  const PeakParams& pp, const int32_t* cand_count, const int64_t* cand_start,
-                                  const int32_t* cand_pos, const uint8_t* state, int32_t* counts,
-                                  const int64_t* out_start, uint8_t* out, int* err) {
-    if (rec.R == 0) return hipSuccess;
+hipError_t launch_peak_eval(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                            int64_t n_cand, const int64_t* cand_rec, const int32_t* cand_pos, const uint8_t* state,
+                            int32_t* accept, double* ips) {
+    if (n_cand == 0) return hipSuccess;
     if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return hipErrorInvalidValue;
-    const unsigned grid = (unsigned)((rec.R + kPeakBlock - 1) / kPeakBlock);
-#define WFA_PL(SRC, F) \
-    hipLaunchKernelGGL((k_find_peaks_list<SRC, F>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, cand_count, cand_start, cand_pos, state, counts, out_start, out, err)
-    if (source == WFA_SRC_RAW) { if (fill) WFA_PL(WFA_SRC_RAW, true); else WFA_PL(WFA_SRC_RAW, false); }
-    else { if (fill) WFA_PL(WFA_SRC_F32, true); else WFA_PL(WFA_SRC_F32, false); }
-#undef WFA_PL
+    const unsigned grid = (unsigned)((n_cand + kPeakBlock - 1) / kPeakBlock);
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_peak_eval<WFA_SRC_RAW>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, n_cand, cand_rec, cand_pos, state, accept, ips);
+    else
+        hipLaunchKernelGGL((k_peak_eval<WFA_SRC_F32>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, n_cand, cand_rec, cand_pos, state, accept, ips);
+    return hipGetLastError();
+}
+
+hipError_t launch_peak_rows(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                            int64_t n_cand, const int64_t* cand_rec, const int32_t* cand_pos, const int32_t* accept,
+                            const int64_t* row_start, const double* ips, uint8_t* out, int* err) {
+    if (n_cand == 0) return hipSuccess;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n_cand + kPeakBlock - 1) / kPeakBlock);
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_peak_rows<WFA_SRC_RAW>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, n_cand, cand_rec, cand_pos, accept, row_start, ips, out, err);
+    else
+        hipLaunchKernelGGL((k_peak_rows<WFA_SRC_F32>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, n_cand, cand_rec, cand_pos, accept, row_start, ips, out, err);
     return hipGetLastError();
 }
 

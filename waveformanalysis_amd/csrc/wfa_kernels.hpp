@@ -125,20 +125,25 @@ hipError_t launch_hits_gather(hipStream_t st, const uint8_t* tmp, const int64_t*
 hipError_t launch_sosfiltfilt(hipStream_t st, const PoolView& pool, const RecView& rec, int n_sections,
                               const double* sos, const double* zi, int edge, int64_t r_begin, int64_t r_end,
                               double* scratch, int64_t batch_stride, float* out);
+hipError_t launch_find_hits_legacy(hipStream_t st, int source, bool fill, const PoolView& pool, int64_t n_rows, int32_t L,
+                                   const double* baselines, double threshold, int32_t* counts, const int64_t* out_start,
+                                   int64_t* out_event, int64_t* out_time);
 hipError_t launch_waveform_width(hipStream_t st, int source, const PoolView& pool, int64_t n_hits,
                                  const int64_t* position, const int64_t* row_index, int64_t n_rows, int32_t L,
                                  double rise_low, double rise_high, double fall_high, double fall_low,
                                  double sampling_rate, int interpolation, uint8_t* out, uint8_t* valid);
-// mode 0/1: count/fill final rows from the stream (distance <= 2); 2/3: count/fill the candidate list
-hipError_t launch_find_peaks(hipStream_t st, int source, int mode, const PoolView& pool, const RecView& rec,
-                             const PeakParams& pp, int32_t* counts, const int64_t* out_start, uint8_t* out,
-                             int32_t* cand_pos, double* cand_val, int* err);
+// find_peaks: candidate scan per record (count / fill), distance selection per record, then per candidate
+hipError_t launch_find_peaks(hipStream_t st, int source, bool fill, const PoolView& pool, const RecView& rec,
+                             const PeakParams& pp, int32_t* counts, const int64_t* out_start, int32_t* cand_pos,
+                             double* cand_val, int64_t* cand_rec);
 hipError_t launch_peak_select(hipStream_t st, int64_t R, const int32_t* counts, const int64_t* cand_start,
                               const int32_t* cand_pos, const double* cand_val, uint8_t* state, int distance);
-hipError_t launch_find_peaks_list(hipStream_t st, int source, bool fill, const PoolView& pool, const RecView& rec,
-                                  const PeakParams& pp, const int32_t* cand_count, const int64_t* cand_start,
-                                  const int32_t* cand_pos, const uint8_t* state, int32_t* counts,
-                                  const int64_t* out_start, uint8_t* out, int* err);
+hipError_t launch_peak_eval(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                            int64_t n_cand, const int64_t* cand_rec, const int32_t* cand_pos, const uint8_t* state,
+                            int32_t* accept, double* ips);
+hipError_t launch_peak_rows(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                            int64_t n_cand, const int64_t* cand_rec, const int32_t* cand_pos, const int32_t* accept,
+                            const int64_t* row_start, const double* ips, uint8_t* out, int* err);
 bool sg_mask_supported(const SgParams& sg);
 hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);

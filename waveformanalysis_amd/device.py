@@ -219,6 +219,20 @@ class DeviceSession:
         _lib.check(self._lib.wfa_find_peaks_fill(self._h, _ptr(out), int(n.value)))
         return out
 
+    def find_hits_legacy(self, source: int, n_rows: int, row_length: int, baselines: np.ndarray,
+                         threshold: float) -> tuple[np.ndarray, np.ndarray]:
+        """(event_index, start sample) of every (baseline - wave) > threshold run on the resident dense matrix."""
+        b = np.ascontiguousarray(baselines, dtype=np.float64)
+        if b.shape != (int(n_rows),):
+            raise ValueError("baselines must hold one value per row")
+        n = C.c_int64(0)
+        _lib.check(self._lib.wfa_find_hits_count(self._h, int(source), int(n_rows), int(row_length), _ptr(b),
+                                                 float(threshold), C.byref(n)))
+        ev = np.empty(int(n.value), dtype=np.int64)
+        t = np.empty(int(n.value), dtype=np.int64)
+        _lib.check(self._lib.wfa_find_hits_fill(self._h, int(n.value), _ptr(ev), _ptr(t)))
+        return ev, t
+
     def waveform_width(self, source: int, position: np.ndarray, row_index: np.ndarray, n_rows: int, row_length: int,
                        rise_low: float = 0.1, rise_high: float = 0.9, fall_high: float = 0.9, fall_low: float = 0.1,
                        sampling_rate: float = 0.5, interpolation: bool = True) -> tuple[np.ndarray, np.ndarray]:

@@ -155,6 +155,12 @@ HIT_MERGED_COMPONENTS_DTYPE = np.dtype([("merged_index", "i8"), ("hit_index", "i
 HIT_MERGE_CLUSTERS_DTYPE = np.dtype([("cluster_index", "i8"), ("hit_index", "i8")])
 
 
+# PEAK_DTYPE of the legacy helpers (reference: processing/dtypes.py:67-77, 30 B)
+PEAK_DTYPE = np.dtype(
+    [("time", "i8"), ("area", "f4"), ("height", "f4"), ("width", "f4"), ("channel", "i2"), ("event_index", "i8")]
+)
+
+
 def create_record_dtype(wave_length: int) -> np.dtype:
     """ST_WAVEFORM_DTYPE with a `wave_length`-sample int16 wave (reference: processing/dtypes.py:36-64)."""
     return np.dtype(
@@ -209,6 +215,7 @@ __all__ = [
     "HIT_MERGED_DTYPE",
     "HIT_MERGED_COMPONENTS_DTYPE",
     "HIT_MERGE_CLUSTERS_DTYPE",
+    "PEAK_DTYPE",
     "create_record_dtype",
     "create_filtered_waveform_dtype",
 ]

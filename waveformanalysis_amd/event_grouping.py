@@ -146,4 +146,104 @@ def group_hit_windows(hits: np.ndarray, time_window_ns: float, dt_values: np.nda
     return pd.DataFrame(rows, columns=EVENT_COLUMNS)
 
 
-__all__ = ["group_hit_windows", "group_hit_windows_flat", "EVENT_COLUMNS"]
+def find_hits(waves: np.ndarray, baselines: np.ndarray, threshold: float, left_extension: int = 2,
+              right_extension: int = 2, session=None) -> np.ndarray:
+    """Legacy vectorised hit finding (event_grouping.py:46-95): contiguous regions of (baseline - wave) > threshold
+    on a dense (n_events, n_samples) array; PEAK_DTYPE rows with `time` = start sample and `event_index` set
+    (the extensions are accepted and unused, as in the reference)."""
+    from . import _lib
+    from .dtypes import PEAK_DTYPE
+
+    waves = np.asarray(waves)
+    if waves.size == 0:
+        return np.zeros(0, dtype=PEAK_DTYPE)
+    if waves.ndim != 2:
+        raise ValueError("waves must be a 2D array (n_events, n_samples)")
+    baselines = np.asarray(baselines, dtype=np.float64)
+    if waves.dtype in (np.int16, np.uint16):
+        flat = np.ascontiguousarray(waves).reshape(-1)
+        if waves.dtype == np.int16:
+            if int(flat.min()) < 0:
+                raise ValueError("waves holds negative samples; the HIP backend reads unsigned ADC codes")
+            flat = flat.view(np.uint16)
+        source = _lib.SRC_RAW
+    elif waves.dtype == np.float32:
+        flat, source = np.ascontiguousarray(waves).reshape(-1), _lib.SRC_F32
+    else:
+        raise ValueError(f"waves must be int16 / uint16 / float32, got {waves.dtype}")
+    if session is None:
+        from .device import default_pool
+
+        session = default_pool().session()
+    session.upload_pool(flat)
+    event_index, start = session.find_hits_legacy(source, waves.shape[0], waves.shape[1], baselines, float(threshold))
+    hits = np.zeros(len(start), dtype=PEAK_DTYPE)
+    hits["event_index"] = event_index
+    hits["time"] = start
+    return hits
+
+
+def find_cluster_boundaries(ts_sorted: np.ndarray, time_window_ps: float) -> np.ndarray:
+    """Fixed-window clustering of sorted timestamps (event_grouping.py:475-525): a cluster takes every hit within
+    `time_window_ps` of its FIRST hit.  All jump targets come from one vectorised searchsorted; the chain of jumps
+    from hit 0 is then followed (one step per event)."""
+    ts_sorted = np.asarray(ts_sorted)
+    n = len(ts_sorted)
+    if n == 0:
+        return np.array([0])
+    nxt = np.searchsorted(ts_sorted, ts_sorted + time_window_ps, side="right")
+    out = [0]
+    cur = 0
+    while cur < n:
+        cur = int(nxt[cur])
+        out.append(cur)
+    return np.array(out)
+
+
+MULTI_CHANNEL_COLUMNS = ["event_id", "t_min", "t_max", "dt/ns", "n_hits", "channels", "areas", "heights", "timestamps"]
+
+
+def group_multi_channel_hits(df, time_window_ns: float, use_numba: bool = True, n_processes: int | None = None):
+    """Legacy DataFrame grouping (event_grouping.py:98-283): sort by timestamp, fixed windows from each cluster's
+    first hit, members ordered by channel.  Table glue on the host; `use_numba` / `n_processes` are accepted and
+    ignored.  The reference sorts with pandas' / numpy's default (unstable) kinds, so the order of equal
+    timestamps, and of equal channels inside an event, is unspecified there; here both sorts are stable."""
+    import pandas as pd
+
+    time_window_ps = time_window_ns * 1e3
+    df_sorted = df.sort_values("timestamp", kind="stable").reset_index(drop=True)
+    area_col = "area" if "area" in df_sorted.columns else "charge"
+    height_col = "height" if "height" in df_sorted.columns else "peak"
+    if area_col not in df_sorted.columns or height_col not in df_sorted.columns:
+        raise KeyError("df must contain area/height (or charge/peak) columns")
+    ts_all = df_sorted["timestamp"].to_numpy()
+    ch_all = df_sorted["channel"].to_numpy()
+    area_all = df_sorted[area_col].to_numpy()
+    height_all = df_sorted[height_col].to_numpy()
+    n = len(df_sorted)
+    if n == 0:
+        return pd.DataFrame(columns=MULTI_CHANNEL_COLUMNS)
+    bounds = find_cluster_boundaries(ts_all, time_window_ps)
+    n_events = len(bounds) - 1
+    event_of = np.repeat(np.arange(n_events), np.diff(bounds))
+    order = np.lexsort((np.arange(n), ch_all, event_of))  # per event: by channel, stable
+    ts_o, ch_o, ar_o, he_o = ts_all[order], ch_all[order], area_all[order], height_all[order]
+    starts, ends = bounds[:-1], bounds[1:]
+    t_min = ts_o[starts].astype(np.int64)       # the reference takes the first / last row AFTER the channel sort
+    t_max = ts_o[ends - 1].astype(np.int64)
+    split = bounds[1:-1]
+    return pd.DataFrame({
+        "event_id": np.arange(n_events, dtype=np.int64),
+        "t_min": t_min,
+        "t_max": t_max,
+        "dt/ns": (ts_o[ends - 1] - ts_o[starts]) / 1e3,
+        "n_hits": np.diff(bounds).astype(np.int32),
+        "channels": np.split(ch_o, split),
+        "areas": np.split(ar_o, split),
+        "heights": np.split(he_o, split),
+        "timestamps": np.split(ts_o, split),
+    })
+
+
+__all__ = ["group_hit_windows", "group_hit_windows_flat", "EVENT_COLUMNS", "find_hits", "find_cluster_boundaries",
+           "group_multi_channel_hits", "MULTI_CHANNEL_COLUMNS"]
