@@ -421,6 +421,51 @@ def legacy_case(name, seed):
           f"{len(out['w40_t_min'])} -> {os.path.getsize(path)} B")
 
 
+def chunk_case(name):
+    """Reference chunk helpers (core/processing/chunk.py): get_endtime, select_time_range, split_by_breaks,
+    check_chunk_boundaries and the Chunk constructor's verdicts on a records table with gaps."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.processing import chunk as C
+
+    rec, _pool = synth.make_run(400, "v1725", cfg=29)
+    rec = rec.copy()
+    rec["timestamp"][150:] += 3 * 10**13      # two breaks
+    rec["timestamp"][300:] += 2 * 10**13
+    rec["time"] = rec["timestamp"] // 1000
+    out = {"records": rec}
+    kw = dict(time_field="timestamp", length_field="event_length")
+    out["endtime"] = C.get_endtime(rec, **kw)
+    out["endtime_dt"] = C.get_endtime(rec, dt=2.5, **kw)
+    t0, t1 = int(rec["timestamp"][40]), int(rec["timestamp"][220])
+    out["sel_bounds"] = np.array([t0, t1], dtype=np.int64)
+    out["sel_loose"] = C.select_time_range(rec, t0, t1, **kw)["record_id"]
+    out["sel_strict"] = C.select_time_range(rec, t0, t1, strict=True, **kw)["record_id"]
+    out["sel_open"] = C.select_time_range(rec, None, t1, **kw)["record_id"]
+    parts = list(C.split_by_breaks(rec, **kw))
+    out["break_first"] = np.array([p[0]["record_id"][0] for p in parts], dtype=np.int64)
+    out["break_info"] = np.array([(i.start_time, i.end_time, i.n_records, i.chunk_i) for _p, i in parts], dtype=np.int64)
+    parts = list(C.split_by_breaks(rec, break_threshold_ps=5 * 10**6, min_chunk_size=3, **kw))
+    out["break2_info"] = np.array([(i.start_time, i.end_time, i.n_records, i.chunk_i) for _p, i in parts], dtype=np.int64)
+    r = C.check_chunk_boundaries(rec, t0, t1, **kw)
+    out["bounds_stats"] = np.array([r.stats["n_records"], r.stats["n_before_start"], r.stats["n_after_end"],
+                                    r.stats["violations"], int(r.is_valid)], dtype=np.int64)
+    out["bounds_errors"] = np.frombuffer("\n".join(r.errors).encode(), dtype=np.uint8)
+    verdicts = []
+    for start, end in ((int(rec["timestamp"].min()), int(out["endtime"].max())), (int(rec["timestamp"].min()) + 1, 10**18),
+                       (0, int(out["endtime"].max()) - 1)):
+        try:
+            C.Chunk(rec, start, end, **kw)
+            verdicts.append("ok")
+        except ValueError as exc:
+            verdicts.append(str(exc))
+    out["chunk_verdicts"] = np.frombuffer("\n".join(verdicts).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(out['break_info'])} / {len(out['break2_info'])} pieces, selections "
+          f"{len(out['sel_loose'])}/{len(out['sel_strict'])}/{len(out['sel_open'])}, verdicts {verdicts} -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -566,6 +611,7 @@ def main():
 
     sort_case("sort_mixed", 31)
     legacy_case("legacy_helpers", 41)
+    chunk_case("chunk_helpers")
 
     # hit merging: real threshold hits of a 16-channel run, and crafted hits whose chains cross records
     merge_cfgs = [{}, {"merge_gap_ns": 20.0}, {"merge_gap_ns": 400.0, "max_total_width_ns": 1500.0},

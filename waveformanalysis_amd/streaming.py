@@ -13,39 +13,15 @@ them to worker threads that each borrow a `DeviceSession` (one HIP stream on one
 from __future__ import annotations
 
 from concurrent.futures import ThreadPoolExecutor
-from dataclasses import dataclass, field
 from typing import Any
 
 import numpy as np
 
 from . import _lib
+from .chunk import Chunk
 from .device import DevicePool, default_pool
 from .dtypes import THRESHOLD_HIT_DTYPE
 from .sg_plan import normalize_window
-
-
-@dataclass
-class Chunk:
-    """Subset of the reference Chunk (core/processing/chunk.py:77-206): data + [start, end) in ps."""
-
-    data: np.ndarray
-    start: int
-    end: int
-    run_id: str = ""
-    data_type: str = ""
-    time_field: str = "timestamp"
-    metadata: dict = field(default_factory=dict)
-
-    def __post_init__(self):
-        if self.end < self.start:
-            raise ValueError(f"Chunk end ({self.end}) < start ({self.start})")
-        if len(self.data) and self.time_field in (self.data.dtype.names or ()):
-            t = self.data[self.time_field]
-            if int(t.min()) < self.start or int(t.max()) >= max(self.end, self.start + 1):
-                raise ValueError("Chunk data outside [start, end)")
-
-    def __len__(self) -> int:
-        return len(self.data)
 
 
 def records_to_chunks(records: np.ndarray, chunk_size: int, run_id: str = "") -> list[Chunk]:
@@ -58,8 +34,8 @@ def records_to_chunks(records: np.ndarray, chunk_size: int, run_id: str = "") ->
         # endtime = time + dt * length (core/processing/chunk.py:388-431), in ps
         endtime = sub["timestamp"].astype(np.int64) + sub["dt"].astype(np.int64) * 1000 * sub["event_length"]
         end = int(endtime.max()) + 1
-        out.append(Chunk(sub, start, end, run_id=run_id, data_type="records",
-                         metadata={"first_record": lo}))
+        out.append(Chunk(sub, start, end, run_id=run_id, data_type="records", data_kind="records",
+                         time_field="timestamp", length_field="event_length", metadata={"first_record": lo}))
     return out
 
 
@@ -88,7 +64,8 @@ class HipThresholdHitStream:
         wave_pool = context.get_data(run_id, "wave_pool")
         recs = chunk.data
         if len(recs) == 0:
-            return Chunk(np.zeros(0, dtype=THRESHOLD_HIT_DTYPE), chunk.start, chunk.end, run_id, self.provides)
+            return Chunk(np.zeros(0, dtype=THRESHOLD_HIT_DTYPE), chunk.start, chunk.end, run_id, self.provides,
+                         data_kind="hits", time_field="timestamp")
         # the chunk's samples are one contiguous slice of the pool for time-sorted records
         lo = int(recs["wave_offset"].min())
         hi = int((recs["wave_offset"].astype(np.int64) + recs["event_length"]).max())
@@ -102,7 +79,8 @@ class HipThresholdHitStream:
             hits = sess.threshold_hits(_lib.SRC_SG_FUSED, self.le, self.re, self.max_len)
         else:
             hits = sess.threshold_hits(_lib.SRC_RAW, self.le, self.re, self.max_len)
-        return Chunk(hits, chunk.start, chunk.end, run_id, self.provides, metadata=dict(chunk.metadata))
+        return Chunk(hits, chunk.start, chunk.end, run_id, self.provides, data_kind="hits", time_field="timestamp",
+                     metadata=dict(chunk.metadata))
 
     def run_chunks(self, chunks: list[Chunk], context: Any, run_id: str, max_workers: int = 4) -> list[Chunk]:
         """Ordered results, chunks processed concurrently (one session / HIP stream per worker)."""
