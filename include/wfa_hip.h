@@ -236,6 +236,14 @@ int wfa_pool_gather(wfa_ctx* ctx, int64_t n_records, const int64_t* src_offset, 
                     const uint16_t* src_pool, int64_t src_samples, int64_t* out_offset, uint16_t* out_pool,
                     int64_t out_samples);
 
+/* Wave index of a CAEN V1725 DAW_DEMO binary stream held in host memory (reference: utils/formats/v1725.py:66-114
+ * `V1725Reader.iter_waves`): 16-byte event header (channel mask in bytes 4 and 11), per set channel a 12-byte
+ * header (size in 32-bit words: 22 bits, truncation flag bit 6 of byte 3, 48-bit timestamp bytes 4-9, uint16 baseline
+ * bytes 10-11) + int16 payload.  Host-only, no context.  Call with capacity 0 to count, then with arrays of n_waves
+ * entries.  payload_offset is in bytes from buf; a short header or payload ends the stream like the reference's reader. */
+int wfa_v1725_index(const uint8_t* buf, int64_t n_bytes, int64_t capacity, int16_t* channel, int64_t* timestamp,
+                    uint8_t* trunc, uint16_t* baseline, int64_t* payload_offset, int32_t* n_samples, int64_t* n_waves);
+
 /* K6 integral-quantile width (reference: waveform_width_integral.py:166-227).
  * out: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B). */
 int wfa_width_integral(wfa_ctx* ctx, int source, double q_low, double q_high, double dt,

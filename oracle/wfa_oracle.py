@@ -846,3 +846,55 @@ def group_multi_channel_hits_literal(ts, ch, area, height, time_window_ns: float
         events.append((int(ts[members[0]]), int(ts[members[-1]]), members))
         cur = nxt
     return events
+
+
+def v1725_waves(blob: bytes):
+    """utils/formats/v1725.py:66-114: (channel, timestamp, trunc, baseline, samples) of every complete wave."""
+    pos, n, out = 0, len(blob), []
+    while n - pos >= 16:
+        head = blob[pos : pos + 16]
+        pos += 16
+        mask = head[4] | (head[11] << 8)
+        for ch in range(16):
+            if not (mask >> ch) & 1:
+                continue
+            if n - pos < 12:
+                return out
+            h = blob[pos : pos + 12]
+            pos += 12
+            words = int.from_bytes(h[:3], "little") & 0x3FFFFF
+            nbytes = (words - 3) << 2
+            if n - pos < nbytes:
+                return out
+            out.append((ch, int.from_bytes(h[4:10], "little"), (h[3] >> 6) & 1, int.from_bytes(h[10:12], "little"),
+                        np.frombuffer(blob[pos : pos + nbytes], dtype=np.int16)))
+            pos += nbytes
+    return out
+
+
+def build_records_from_v1725_blobs(blobs, boards, dt_ns: int):
+    """records_builder.py:164-209 + 797-830: one sorted part per file (python loop over waves), heap merge."""
+    parts = []
+    for blob, board in zip(blobs, boards):
+        waves = v1725_waves(bytes(blob))
+        if not waves:
+            continue
+        rec = np.zeros(len(waves), dtype=RECORDS_DTYPE)
+        for i, (ch, ts, trunc, bl, w) in enumerate(waves):
+            rec[i]["timestamp"] = ts * dt_ns * 1000
+            rec[i]["board"], rec[i]["channel"], rec[i]["baseline"] = board, ch, bl
+            rec[i]["baseline_upstream"], rec[i]["polarity"], rec[i]["dt"] = np.nan, "unknown", dt_ns
+            rec[i]["flags"], rec[i]["event_length"], rec[i]["time"] = trunc, len(w), (ts * dt_ns * 1000) // 1000
+        order = records_sort_order(rec)
+        rec = rec[order]
+        chunks, cursor = [], 0
+        for k, src in enumerate(order):
+            w = waves[int(src)][4]
+            rec["wave_offset"][k] = cursor
+            chunks.append(w.astype(np.uint16))
+            cursor += len(w)
+        rec["record_id"] = np.arange(len(rec))
+        parts.append((rec, np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint16)))
+    if not parts:
+        return np.zeros(0, dtype=RECORDS_DTYPE), np.zeros(0, dtype=np.uint16)
+    return parts[0] if len(parts) == 1 else merge_records_parts(parts)

@@ -466,6 +466,68 @@ def chunk_case(name):
           f"{len(out['sel_loose'])}/{len(out['sel_strict'])}/{len(out['sel_open'])}, verdicts {verdicts} -> {os.path.getsize(path)} B")
 
 
+def v1725_blob(rng, n_events, t0):
+    """A DAW_DEMO byte stream (layout: utils/formats/v1725.py:66-114): n_events events, 1-5 channels each."""
+    out = bytearray()
+    t = t0
+    for _ in range(n_events):
+        t += int(rng.integers(0, 4000))
+        chans = np.sort(rng.choice(16, size=int(rng.integers(1, 6)), replace=False))
+        mask = int(sum(1 << int(c) for c in chans))
+        eh = bytearray(16)
+        eh[4] = mask & 0xFF
+        eh[11] = (mask >> 8) & 0xFF
+        eh[0:4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))   # fields the reader ignores
+        out += eh
+        for _c in chans:
+            n_samp = int(rng.choice([8, 64, 200, 0, 30])) * 2
+            payload = rng.integers(0, 16384, n_samp).astype(np.int16).tobytes()
+            ch = bytearray(12)
+            size = 3 + len(payload) // 4
+            ch[0], ch[1], ch[2] = size & 0xFF, (size >> 8) & 0xFF, (size >> 16) & 0x3F
+            ch[3] = 0x40 if rng.random() < 0.2 else 0
+            ch[3] |= int(rng.integers(0, 64))                        # other bits of byte 3 are not the flag
+            ch[4:10] = int(t + int(rng.integers(0, 3))).to_bytes(6, "little")
+            ch[10:12] = int(rng.integers(7800, 8200)).to_bytes(2, "little")
+            out += ch + payload
+    return bytes(out)
+
+
+def v1725_case(name, seed):
+    """Reference build_records_from_v1725_files (records_builder.py:797-830) and V1725Reader.iter_waves on three
+    files of two boards, one of them cut in the middle of a waveform."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.processing.records_builder import build_records_from_v1725_files
+    from waveform_analysis.utils.formats.v1725 import V1725Reader
+
+    rng = np.random.default_rng(seed)
+    blobs = {"run_b0_seg0.bin": v1725_blob(rng, 45, 10**6), "run_b0_seg1.bin": v1725_blob(rng, 30, 10**6 + 60000),
+             "run_b1_seg0.bin": v1725_blob(rng, 40, 10**6 + 500)}
+    blobs["run_b0_seg1.bin"] = blobs["run_b0_seg1.bin"][:-37]       # short waveform at the end
+    tmp = tempfile.mkdtemp(prefix="wfa_v1725_")
+    paths = []
+    out = {}
+    for k, (fname, blob) in enumerate(blobs.items()):
+        path = os.path.join(tmp, fname)
+        with open(path, "wb") as f:
+            f.write(blob)
+        paths.append(path)
+        out[f"blob{k}"] = np.frombuffer(blob, dtype=np.uint8)
+        waves = list(V1725Reader().iter_waves([path]))
+        out[f"index{k}"] = np.array([(w.channel, w.timestamp, int(w.trunc), w.baseline, len(w.waveform)) for w in waves],
+                                    dtype=np.int64)
+    out["names"] = np.frombuffer("\n".join(blobs).encode(), dtype=np.uint8)
+    b = build_records_from_v1725_files(paths, dt_ns=4)
+    out["records"], out["wave_pool"] = b.records, b.wave_pool
+    b1 = build_records_from_v1725_files(paths[2:], dt_ns=2)
+    out["records_single"], out["wave_pool_single"] = b1.records, b1.wave_pool
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: waves per file {[len(out[f'index{k}']) for k in range(3)]}, merged {len(b.records)} rec / "
+          f"{len(b.wave_pool)} samples -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -612,6 +674,7 @@ def main():
     sort_case("sort_mixed", 31)
     legacy_case("legacy_helpers", 41)
     chunk_case("chunk_helpers")
+    v1725_case("v1725bin_files", 51)
 
     # hit merging: real threshold hits of a 16-channel run, and crafted hits whose chains cross records
     merge_cfgs = [{}, {"merge_gap_ns": 20.0}, {"merge_gap_ns": 400.0, "max_total_width_ns": 1500.0},

@@ -152,4 +152,85 @@ def merge_records_parts(parts: Sequence[RecordsBundle], session=None) -> Records
     return RecordsBundle(records=out, wave_pool=pool)
 
 
-__all__ = ["RecordsBundle", "records_sort_order", "build_records_from_st_waveforms", "merge_records_parts"]
+def v1725_index(blob: np.ndarray) -> dict:
+    """Per-wave header fields and payload positions of a V1725 DAW_DEMO byte stream (utils/formats/v1725.py:66-114)."""
+    import ctypes as C
+
+    from . import _lib
+
+    buf = np.ascontiguousarray(blob, dtype=np.uint8)
+    lib = _lib.load()
+    n = C.c_int64(0)
+    ptr = buf.ctypes.data_as(C.c_void_p)
+    _lib.check(lib.wfa_v1725_index(ptr, buf.size, 0, None, None, None, None, None, None, C.byref(n)))
+    k = int(n.value)
+    out = {"channel": np.empty(k, np.int16), "timestamp": np.empty(k, np.int64), "trunc": np.empty(k, np.uint8),
+           "baseline": np.empty(k, np.uint16), "payload_offset": np.empty(k, np.int64), "n_samples": np.empty(k, np.int32)}
+    _lib.check(lib.wfa_v1725_index(ptr, buf.size, k, *[out[f].ctypes.data_as(C.c_void_p) for f in (
+        "channel", "timestamp", "trunc", "baseline", "payload_offset", "n_samples")], C.byref(n)))
+    return out
+
+
+def _board_from_path(path) -> int:
+    import os
+    import re
+
+    m = re.search(r"_b(\d+)", os.path.basename(str(path)), flags=re.IGNORECASE)
+    return int(m.group(1)) if m else 0
+
+
+def build_records_from_v1725_blob(blob: np.ndarray, board: int, dt_ns: int, session=None) -> RecordsBundle:
+    """One file's worth of waves -> sorted records + packed pool (records_builder.py:164-209 after the reader):
+    header walk on the host, order and payload packing on the GPU straight from the file bytes."""
+    idx = v1725_index(blob)
+    n = len(idx["channel"])
+    if n == 0:
+        return _empty()
+    rec = np.zeros(n, dtype=RECORDS_DTYPE)
+    rec["timestamp"] = idx["timestamp"] * np.int64(int(dt_ns) * 1000)   # SAMPLE_INDEX mode (formats/base.py:177-185)
+    rec["pid"] = 0
+    rec["board"] = board
+    rec["channel"] = idx["channel"]
+    rec["baseline"] = idx["baseline"].astype(np.float64)
+    rec["baseline_upstream"] = np.nan
+    rec["polarity"] = "unknown"
+    rec["dt"] = np.int32(dt_ns)
+    rec["trigger_type"] = 0
+    rec["flags"] = idx["trunc"].astype(np.uint32)
+    rec["event_length"] = idx["n_samples"]
+    rec["time"] = rec["timestamp"] // 1000
+    sess = _session(session)
+    order = records_sort_order(rec, sess)
+    rec = rec[order]
+    buf = np.ascontiguousarray(blob, dtype=np.uint8)
+    if buf.size % 2:
+        buf = np.concatenate([buf, np.zeros(1, dtype=np.uint8)])
+    out_off, pool = sess.pool_gather(idx["payload_offset"][order] // 2, rec["event_length"], buf.view(np.uint16))
+    rec["wave_offset"] = out_off
+    rec["record_id"] = np.arange(n, dtype=np.int64)
+    return RecordsBundle(records=rec, wave_pool=pool)
+
+
+def build_records_from_v1725_files(file_paths, dt_ns: int, session=None) -> RecordsBundle:
+    """records_builder.py:797-830: one sorted part per file, parts merged."""
+    import os
+
+    if not file_paths:
+        return _empty()
+    sess = _session(session)
+    parts = []
+    for path in file_paths:
+        if not os.path.exists(path):   # the reference's reader logs a warning and goes on
+            continue
+        part = build_records_from_v1725_blob(np.fromfile(path, dtype=np.uint8), _board_from_path(path), dt_ns, sess)
+        if len(part.records):
+            parts.append(part)
+    if not parts:
+        return _empty()
+    if len(parts) == 1:
+        return parts[0]
+    return merge_records_parts(parts, sess)
+
+
+__all__ = ["RecordsBundle", "records_sort_order", "build_records_from_st_waveforms", "merge_records_parts",
+           "v1725_index", "build_records_from_v1725_blob", "build_records_from_v1725_files"]
