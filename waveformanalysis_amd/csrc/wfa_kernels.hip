@@ -1753,18 +1753,38 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     // Interior samples: sig = +-(b - f64(y32)) is strictly monotone in y32 as long as the float64
     // subtraction is exact, which holds for |b| < 2^18 and |y| < 2^17 (difference needs < 53 bits).
     // Then the first maximum of sig is the first extremum of y32: a float32 compare per sample
-    // instead of a float64 compare chain; sig itself is only needed for the integral.
+    // instead of a float64 compare chain; sig itself is only needed for the integral.  Both polarities run the
+    // same code on t = +-y32 (one xor on the sign bit): sig = sb - f64(t) with sb = +-b, first minimum of t.
+    // The loop body is straight-line (selects, no per-sample branch: the branchy form cost 15 scalar
+    // instructions and two jumps per sample).  A baseline outside the exact range sends the hit to the literal kernel.
     const bool y_order = fabs(baseline) < 262144.0;
-    float ext_y = positive ? -__builtin_huge_valf() : __builtin_huge_valf();
+    if (work && !y_order) need_literal = true;
+    const uint32_t sign_mask = positive ? 0x80000000u : 0u;
+    const double sb = positive ? -baseline : baseline;
+    float ext_t = __builtin_huge_valf();
     int ext_i = 0x7fffffff;
     const int wlen = ihi - ilo;
+    int y_num_min = INT32_MAX;
     // rounds: the whole wave iterates while any group has chunks left
+    // unconditional load at a clamped index (a load behind a branch drags an `s_waitcnt vmcnt(0)` with it): chunks
+    // outside [0, c_last + 1] only feed samples that are not in the window (record edges, finished groups); the pool
+    // buffer has 256 B of slack behind its end
+    const int64_t c_hi_load = has_int ? c_last + 1 : 0;
+    auto load_round = [&](int64_t c) {
+        int64_t m = c - 1 + q;
+        m = m < 0 ? 0 : (m > c_hi_load ? c_hi_load : m);
+        return p16[m];
+    };
+    uint4 v = load_round(c_first);
     for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 6) {
         const int64_t mine = c - 1 + q;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c <= c_last && mine >= 0 && mine <= c_last + 1) v = p16[mine];  // pool has 256 B of slack
         uint32_t E[12];
         E[4] = v.x ^ 0x80008000u; E[5] = v.y ^ 0x80008000u; E[6] = v.z ^ 0x80008000u; E[7] = v.w ^ 0x80008000u;
+        // the scheduler must not lift the next load above these four reads: the compiler cannot count a load that is
+        // in flight across the back-edge and would wait for `vmcnt(0)`, i.e. for the prefetch it has just issued
+        __builtin_amdgcn_sched_barrier(0);
+        v = load_round(c + 6);  // next round's chunk is in flight while this one is evaluated
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             E[k] = dpp_from_prev_lane(0u, E[4 + k]);
@@ -1772,30 +1792,27 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
         }
         int Z[8];
         sg_chunk_numerators<W>(E, cpm, Z);
-        if (q >= 1 && q <= 6 && mine <= c_last) {
-            const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
+        const bool lane_ok = q >= 1 && q <= 6 && mine <= c_last;
+        const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int rel = rel0 + j;
-                if ((unsigned)rel < (unsigned)wlen) {
-                    const int y_num = Z[j] + bias_i;
-                    need_literal |= y_num < guard;
-                    const float y32 = (float)((double)y_num * sg.rden);
-                    const double sgn = positive ? ((double)y32 - baseline) : (baseline - (double)y32);
-                    if (y_order) {
-                        const bool better = positive ? (y32 > ext_y) : (y32 < ext_y);  // ascending rel: first kept
-                        ext_y = better ? y32 : ext_y;
-                        ext_i = better ? ilo + rel : ext_i;
-                        acc.sum += sgn > 0.0 ? sgn : 0.0;
-                    } else {
-                        acc.add(sgn, ilo + rel);
-                    }
-                }
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int rel = rel0 + j;
+            const bool in = lane_ok && (unsigned)rel < (unsigned)wlen;
+            const int y_num = Z[j] + bias_i;
+            const int y_chk = in ? y_num : INT32_MAX;
+            y_num_min = y_chk < y_num_min ? y_chk : y_num_min;
+            const float y32 = (float)((double)y_num * sg.rden);
+            const float t = __uint_as_float(__float_as_uint(y32) ^ sign_mask);
+            const bool better = in && t < ext_t;  // ascending rel: the first extremum is kept
+            ext_t = better ? t : ext_t;
+            ext_i = better ? ilo + rel : ext_i;
+            const double sgn = sb - (double)t;
+            acc.sum += (in && sgn > 0.0) ? sgn : 0.0;
         }
     }
-    if (y_order && ext_i != 0x7fffffff) {
-        acc.best = positive ? ((double)ext_y - baseline) : (baseline - (double)ext_y);
+    need_literal |= y_num_min < guard;
+    if (ext_i != 0x7fffffff) {
+        acc.best = sb - (double)ext_t;
         acc.best_i = ext_i;
     }
     if (__ballot(work && (seg_start < H || seg_end > L - H)) != 0) {
