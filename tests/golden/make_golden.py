@@ -528,6 +528,46 @@ def v1725_case(name, seed):
           f"{len(b.wave_pool)} samples -> {os.path.getsize(path)} B")
 
 
+def stream_case(name):
+    """Reference StreamingPlugin (core/plugins/core/streaming.py): chunks it cuts from a static records table with
+    breaks and a halo, and what an identity plugin yields after clipping (serial path)."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.plugins.core.streaming import StreamingPlugin
+
+    rec, _pool = synth.make_run(500, "v1725", cfg=30)
+    rec = rec.copy()
+    rec["timestamp"][180:] += 4 * 10**13
+    rec["timestamp"][390:] += 2 * 10**13
+
+    class Identity(StreamingPlugin):
+        provides = "ident"
+        depends_on = ["records"]
+        chunk_size = 64
+        length_field = "event_length"
+        parallel = False
+
+    out = {"records": rec}
+    for tag, kw in (("a", dict(required_halo_ns=0)), ("b", dict(required_halo_ns=40_000_000)),
+                    ("c", dict(required_halo_left_ns=15_000_000, required_halo_right_ns=0, clip_strict=True, chunk_size=100)),
+                    ("d", dict(break_threshold_ps=0, chunk_size=200))):
+        p = Identity()
+        p._apply_streaming_config(kw)     # compute() resets these keys from the class defaults + streaming_config
+        chunks = list(p._data_to_chunks(rec, "run"))
+        out[f"{tag}_in"] = np.array([(c.start, c.end, c.metadata["main_start"], c.metadata["main_end"],
+                                       c.metadata["segment_id"], len(c), int(c.data["record_id"][0]),
+                                       int(c.data["record_id"][-1])) for c in chunks], dtype=np.int64)
+        res = list(p.compute(Ctx({}, {"records": rec}), "run", streaming_config=dict(kw)))
+        out[f"{tag}_out"] = np.array([(c.start, c.end, len(c), int(c.data["record_id"][0]), int(c.data["record_id"][-1]))
+                                       for c in res], dtype=np.int64)
+    out["options_json"] = np.frombuffer(json.dumps({"a": {"required_halo_ns": 0}, "b": {"required_halo_ns": 40000000},
+        "c": {"required_halo_left_ns": 15000000, "required_halo_right_ns": 0, "clip_strict": True, "chunk_size": 100},
+        "d": {"break_threshold_ps": 0, "chunk_size": 200}}).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: chunks in/out {[(len(out[t + '_in']), len(out[t + '_out'])) for t in 'abcd']} -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -674,6 +714,7 @@ def main():
     sort_case("sort_mixed", 31)
     legacy_case("legacy_helpers", 41)
     chunk_case("chunk_helpers")
+    stream_case("chunk_streaming")
     v1725_case("v1725bin_files", 51)
 
     # hit merging: real threshold hits of a 16-channel run, and crafted hits whose chains cross records

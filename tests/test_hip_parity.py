@@ -246,6 +246,17 @@ def test_streaming_chunks_with_device_pool():
             want = O.threshold_hits_chunked(rec, O.filter_wave_pool_uniform(pool, 800) if use_filtered else pool)
             G.assert_struct_equal(got, want, float_rtol=FLOAT_RTOL, what=f"stream filtered={use_filtered}")
             assert all(o.start == c.start and o.end == c.end for o, c in zip(outs, chunks))
+            # the generator entry point: the base class cuts `records` at time breaks / chunk_size, halo records are
+            # processed twice and clipped away again, results arrive in input order
+            rec2 = rec.copy()
+            rec2["timestamp"][1500:] += 3 * 10**13
+            ctx2 = SimpleContext({}, {"records": rec2, "wave_pool": pool})
+            want2 = O.threshold_hits_chunked(rec2, O.filter_wave_pool_uniform(pool, 800) if use_filtered else pool)
+            for cfg in ({"chunk_size": 400, "max_workers": 3}, {"chunk_size": 1000, "required_halo_ns": 30_000_000, "parallel": False}):
+                outs = list(plugin.compute(ctx2, "run", streaming_config=cfg))
+                assert len(outs) >= 3 and {o.metadata["segment_id"] for o in outs} == {0, 1}
+                G.assert_struct_equal(np.concatenate([c.data for c in outs]), want2, float_rtol=FLOAT_RTOL,
+                                      what=f"stream generator {cfg}")
     finally:
         dp.close()
 

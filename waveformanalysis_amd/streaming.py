@@ -18,10 +18,242 @@ from typing import Any
 import numpy as np
 
 from . import _lib
-from .chunk import Chunk
+from .chunk import (
+    DEFAULT_BREAK_THRESHOLD_PS,
+    DT_FIELD,
+    ENDTIME_FIELD,
+    LENGTH_FIELD,
+    TIME_FIELD,
+    TIMESTAMP_FIELD,
+    Chunk,
+    check_chunk_boundaries,
+    get_endtime,
+    select_time_range,
+    split_by_breaks,
+)
 from .device import DevicePool, default_pool
 from .dtypes import THRESHOLD_HIT_DTYPE
 from .sg_plan import normalize_window
+
+
+def _pick_time_field(data, preferred: str):
+    """streaming.py:105-116."""
+    if not hasattr(data, "dtype") or data.dtype.names is None:
+        return None
+    if preferred in data.dtype.names:
+        return preferred
+    if preferred == TIME_FIELD and TIMESTAMP_FIELD in data.dtype.names:
+        return TIMESTAMP_FIELD
+    if preferred == TIMESTAMP_FIELD and TIME_FIELD in data.dtype.names:
+        return TIME_FIELD
+    return None
+
+
+class HipStreamingPlugin:
+    """Chunk-stream driver with the knobs and the chunking rules of the reference's StreamingPlugin
+    (core/plugins/core/streaming.py:119-176, 318-360, 380-445, 463-545, 592-691, 882-910):
+
+    * a static structured array is cut into segments at time breaks (`break_threshold_ps`), segments into chunks of
+      `chunk_size` rows, each chunk widened by the halo and carrying its core range as metadata main_start/main_end;
+    * `compute_chunk` results are wrapped, clipped back to the core range (`clip_strict`) and boundary-checked;
+    * `compute()` is a generator that yields the results in input order; chunks run concurrently on worker threads,
+      each borrowing a DeviceSession (one HIP stream on one GPU) from a DevicePool -- where the reference submits to
+      its ExecutorManager -- unless the plugin is stateful (serial, `reset_state()` at every new segment).
+    """
+
+    provides = "stream"
+    depends_on: list = []
+    output_kind = "stream"
+    chunk_size: int = 50000
+    parallel: bool = True
+    parallel_batch_size = None
+    executor_type: str = "thread"
+    max_workers = None
+    time_field: str = TIMESTAMP_FIELD
+    dt_field: str = DT_FIELD
+    length_field: str = LENGTH_FIELD
+    endtime_field: str = ENDTIME_FIELD
+    dt = None
+    output_time_field: str = TIMESTAMP_FIELD
+    output_endtime_field: str = ENDTIME_FIELD
+    output_data_kind: str = "stream"
+    required_halo_ns: int = 0
+    required_halo_left_ns: int = 0
+    required_halo_right_ns: int = 0
+    clip_strict: bool = False
+    is_stateful: bool = False
+    reset_on_break: bool = True
+    break_threshold_ps: int = DEFAULT_BREAK_THRESHOLD_PS
+    device_pool = None
+
+    # -- to override --------------------------------------------------------------------------------------
+    def compute_chunk(self, chunk: Chunk, context: Any, run_id: str, **kwargs):
+        return chunk
+
+    def reset_state(self) -> None:
+        return None
+
+    # -- chunking -----------------------------------------------------------------------------------------
+    def _get_required_halo(self) -> tuple[int, int]:
+        left = self.required_halo_left_ns or 0
+        right = self.required_halo_right_ns or 0
+        if self.required_halo_ns:
+            left, right = max(left, self.required_halo_ns), max(right, self.required_halo_ns)
+        return int(left), int(right)
+
+    def _time_kw(self) -> dict:
+        return dict(endtime_field=self.endtime_field, dt_field=self.dt_field, length_field=self.length_field, dt=self.dt)
+
+    def _endtime_of(self, data: np.ndarray, time_field: str) -> np.ndarray:
+        """End of every row in the units of `time_field`; the reference's rule is time + dt * length (chunk.py:263-306).
+        Subclasses whose time field and dt use different units override this (see HipThresholdHitStream)."""
+        return get_endtime(data, time_field=time_field, **self._time_kw())
+
+    def _iter_segments(self, data: np.ndarray, time_field: str):
+        if self.break_threshold_ps and self.break_threshold_ps > 0:
+            for seg_id, (seg, info) in enumerate(split_by_breaks(data, break_threshold_ps=self.break_threshold_ps,
+                                                                 min_chunk_size=1, time_field=time_field,
+                                                                 **self._time_kw())):
+                yield seg, int(info.start_time), int(np.max(self._endtime_of(seg, time_field))), seg_id
+            return
+        if len(data) == 0:
+            return
+        yield data, int(np.min(data[time_field])), int(np.max(self._endtime_of(data, time_field))), 0
+
+    def _data_to_chunks(self, data: Any, run_id: str):
+        if not isinstance(data, np.ndarray):
+            raise TypeError("the HIP streaming driver chunks numpy arrays (or takes a chunk iterator as it is)")
+        tf = _pick_time_field(data, self.time_field)
+        if tf:
+            halo_left, halo_right = self._get_required_halo()
+            for seg, seg_start, seg_end, seg_id in self._iter_segments(data, tf):
+                for i in range(0, len(seg), self.chunk_size):
+                    main = seg[i : i + self.chunk_size]
+                    if len(main) == 0:
+                        continue
+                    main_start = int(np.min(main[tf]))
+                    main_end = int(np.max(self._endtime_of(main, tf)))
+                    ext_start = max(seg_start, main_start - halo_left)
+                    ext_end = min(seg_end, main_end + halo_right)
+                    ext = select_time_range(seg, start=ext_start, end=ext_end, strict=False, time_field=tf,
+                                            **self._time_kw())
+                    yield Chunk(ext, ext_start, ext_end, run_id=run_id, data_type=self.provides, time_field=tf,
+                                metadata={"main_start": main_start, "main_end": main_end, "segment_id": seg_id},
+                                **self._time_kw())
+            return
+        for i in range(0, len(data), self.chunk_size):
+            part = data[i : i + self.chunk_size]
+            if len(part) == 0:
+                continue
+            yield Chunk(part, i, i + len(part), run_id=run_id, data_type=self.provides, time_field=self.time_field,
+                        metadata={"main_start": i, "main_end": i + len(part), "segment_id": 0}, **self._time_kw())
+
+    def _get_input_chunks(self, context: Any, run_id: str, **kwargs):
+        deps = self.resolve_depends_on(context, run_id=run_id) if hasattr(self, "resolve_depends_on") else self.depends_on
+        if not deps:
+            return iter([])
+        dep = context.get_data(run_id, deps[0])
+        if hasattr(dep, "__next__") or (hasattr(dep, "__iter__") and not isinstance(dep, (np.ndarray, list))):
+            return dep
+        return self._data_to_chunks(dep, run_id)
+
+    # -- results ------------------------------------------------------------------------------------------
+    def _postprocess_result(self, result: Any, input_chunk: Chunk):
+        if result is None:
+            return None
+        if not isinstance(result, Chunk):
+            result = Chunk(np.asarray(result), input_chunk.metadata.get("main_start", input_chunk.start),
+                           input_chunk.metadata.get("main_end", input_chunk.end), run_id=input_chunk.run_id,
+                           data_type=self.provides, data_kind=self.output_data_kind, time_field=self.output_time_field,
+                           dt_field=self.dt_field, length_field=self.length_field,
+                           endtime_field=self.output_endtime_field, dt=self.dt,
+                           metadata={"segment_id": input_chunk.metadata.get("segment_id")})
+        main_start, main_end = input_chunk.metadata.get("main_start"), input_chunk.metadata.get("main_end")
+        if main_start is None or main_end is None:
+            return result
+        if not hasattr(result.data, "dtype") or result.data.dtype.names is None:
+            return result
+        clipped = select_time_range(result.data, start=main_start, end=main_end, strict=self.clip_strict,
+                                    time_field=result.time_field, endtime_field=result.endtime_field,
+                                    dt_field=result.dt_field, length_field=result.length_field, dt=result.dt)
+        if len(clipped) == 0:
+            return None
+        meta = dict(result.metadata)
+        meta.update({"main_start": main_start, "main_end": main_end,
+                     "segment_id": input_chunk.metadata.get("segment_id")})
+        return Chunk(clipped, int(main_start), int(main_end), run_id=result.run_id, data_type=result.data_type,
+                     data_kind=result.data_kind, time_field=result.time_field, dt_field=result.dt_field,
+                     length_field=result.length_field, endtime_field=result.endtime_field, dt=result.dt, metadata=meta)
+
+    def _validate_chunk(self, chunk: Chunk) -> None:
+        if len(chunk.data) == 0 or not hasattr(chunk.data, "dtype") or chunk.data.dtype.names is None:
+            return
+        v = check_chunk_boundaries(chunk.data, chunk.start, chunk.end, time_field=chunk.time_field,
+                                   endtime_field=chunk.endtime_field, dt_field=chunk.dt_field,
+                                   length_field=chunk.length_field, dt=chunk.dt)
+        if not v.is_valid:
+            raise ValueError(f"Chunk boundary violation in {self.provides}: {v.errors}")
+
+    def _process(self, chunk: Chunk, context: Any, run_id: str, kwargs: dict):
+        result = self._postprocess_result(self.compute_chunk(chunk, context, run_id, **kwargs), chunk)
+        if result is not None:
+            self._validate_chunk(result)
+        return result
+
+    # -- driver -------------------------------------------------------------------------------------------
+    STREAMING_CONFIG_KEYS = ("chunk_size", "parallel", "executor_type", "max_workers", "parallel_batch_size",
+                             "break_threshold_ps", "required_halo_ns", "required_halo_left_ns",
+                             "required_halo_right_ns", "clip_strict")
+
+    def _apply_streaming_config(self, streaming_config) -> None:
+        """streaming.py:264-316: every run starts from the CLASS defaults, then `streaming_config` (a dict) wins;
+        unknown keys are reported and dropped."""
+        if streaming_config is not None and not isinstance(streaming_config, dict):
+            raise TypeError("streaming_config must be a dict")
+        merged = {k: getattr(type(self), k, getattr(self, k, None)) for k in self.STREAMING_CONFIG_KEYS}
+        unknown = []
+        for key, value in (streaming_config or {}).items():
+            if key in merged:
+                merged[key] = value
+            elif key != "executor_config":
+                unknown.append(key)
+        if unknown:
+            import warnings
+
+            warnings.warn(f"Unknown streaming_config keys for {self.provides}: {sorted(unknown)}", UserWarning, stacklevel=3)
+        for key, value in merged.items():
+            setattr(self, key, value)
+
+    def compute(self, context: Any, run_id: str, **kwargs):
+        self._apply_streaming_config(kwargs.pop("streaming_config", None))
+        chunks = self._get_input_chunks(context, run_id, **kwargs)
+        parallel = self.parallel and not self.is_stateful and (self.max_workers is None or self.max_workers > 1)
+        if not parallel:
+            last_segment = None
+            for chunk in chunks:
+                if self.is_stateful and self.reset_on_break:
+                    seg = chunk.metadata.get("segment_id")
+                    if seg is not None and seg != last_segment:
+                        self.reset_state()
+                        last_segment = seg
+                result = self._process(chunk, context, run_id, kwargs)
+                if result is not None:
+                    yield result
+            return
+        workers = int(self.max_workers or 4)
+        batch = int(self.parallel_batch_size or 2 * workers)
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            pending = []
+            for chunk in chunks:
+                pending.append(ex.submit(self._process, chunk, context, run_id, kwargs))
+                if len(pending) >= batch:
+                    result = pending.pop(0).result()
+                    if result is not None:
+                        yield result
+            for fut in pending:
+                result = fut.result()
+                if result is not None:
+                    yield result
 
 
 def records_to_chunks(records: np.ndarray, chunk_size: int, run_id: str = "") -> list[Chunk]:
@@ -39,16 +271,35 @@ def records_to_chunks(records: np.ndarray, chunk_size: int, run_id: str = "") ->
     return out
 
 
-class HipThresholdHitStream:
-    """compute_chunk() = threshold hits of one chunk of records (fused SG filter optional)."""
+class HipThresholdHitStream(HipStreamingPlugin):
+    """compute_chunk() = threshold hits of one chunk of records (fused SG filter optional).
+
+    `compute(context, run_id)` streams over the static `records` array with the base class's chunking (breaks at
+    10^13 ps, 50 000 records per chunk); hits are instantaneous rows (time = `timestamp`), clipped to the chunk's core
+    range like any stream output."""
 
     provides = "hit_threshold_stream"
     depends_on = ["records", "wave_pool"]
     output_dtype = THRESHOLD_HIT_DTYPE
-    output_kind = "stream"
     chunk_size = 50_000          # reference default (streaming.py:153-176)
-    parallel = True
-    is_stateful = False
+    length_field = "event_length"
+    output_data_kind = "hits"
+
+    def _endtime_of(self, data: np.ndarray, time_field: str) -> np.ndarray:
+        # records: timestamp in ps, dt in ns per sample -> the end of a record in ps
+        return data[time_field].astype(np.int64) + data["dt"].astype(np.int64) * 1000 * data["event_length"].astype(np.int64)
+
+    def _data_to_chunks(self, data: Any, run_id: str):
+        """Records of different channels overlap in time, so time-range chunks (the base rule) share records at
+        their borders and every shared record's hits would come out twice.  Hits depend on their own record only:
+        a chunk is `chunk_size` consecutive records of a time segment, nothing is widened and nothing clipped
+        (no main_start / main_end in the metadata)."""
+        if not isinstance(data, np.ndarray) or data.dtype.names is None:
+            raise TypeError("hit_threshold_stream chunks the structured `records` array")
+        for seg, _s, _e, seg_id in self._iter_segments(data, "timestamp"):
+            for ch in records_to_chunks(seg, self.chunk_size, run_id):
+                ch.metadata["segment_id"] = seg_id
+                yield ch
 
     def __init__(self, threshold: float = 10.0, left_extension: int = 2, right_extension: int = 2,
                  use_filtered: bool = False, sg_window_size: int = 11, sg_poly_order: int = 2,
@@ -79,7 +330,10 @@ class HipThresholdHitStream:
             hits = sess.threshold_hits(_lib.SRC_SG_FUSED, self.le, self.re, self.max_len)
         else:
             hits = sess.threshold_hits(_lib.SRC_RAW, self.le, self.re, self.max_len)
-        return Chunk(hits, chunk.start, chunk.end, run_id, self.provides, data_kind="hits", time_field="timestamp",
+        # a record that overlaps the chunk's end (non-strict halo selection) has hits behind it: the result chunk
+        # spans every record it was computed from; the driver clips it back to the core range
+        end = max(int(chunk.end), int(self._endtime_of(recs, "timestamp").max()) + 1)
+        return Chunk(hits, chunk.start, end, run_id, self.provides, data_kind="hits", time_field="timestamp",
                      metadata=dict(chunk.metadata))
 
     def run_chunks(self, chunks: list[Chunk], context: Any, run_id: str, max_workers: int = 4) -> list[Chunk]:
@@ -90,4 +344,4 @@ class HipThresholdHitStream:
             return list(ex.map(lambda c: self.compute_chunk(c, context, run_id), chunks))
 
 
-__all__ = ["Chunk", "records_to_chunks", "HipThresholdHitStream"]
+__all__ = ["Chunk", "records_to_chunks", "HipStreamingPlugin", "HipThresholdHitStream"]
