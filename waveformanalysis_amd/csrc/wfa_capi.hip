@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <new>
 
+#include <algorithm>
+
 #include "wfa_common.hpp"
 #include "wfa_kernels.hpp"
 
@@ -193,12 +195,54 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             if ((rc = t.end("k_scan(hit counts)"))) return rc;
         }
         int64_t total = 0;
-        WFA_HIP_CHECK(hipMemcpyAsync(&total, c->scan_blocks.as<int64_t>() + nb, sizeof(int64_t),
-                                     hipMemcpyDeviceToHost, c->stream));
-        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
-        if ((rc = c->hit_out.ensure((size_t)total * 60))) return rc;
-        if ((rc = c->hit_desc.ensure((size_t)total * sizeof(int4)))) return rc;
+        const int64_t* d_total = c->scan_blocks.as<int64_t>() + nb;
         RowParams rp{le, re, max_len, sp0.W / 2};
+        // Speculative tail: a pass usually finds about as many hits as the previous one on this context.  When the
+        // row buffers already hold that many (+12 %), the row kernels are launched for that bound straight away and
+        // take the real count from the device; the host reads it once, after everything is queued.  A pass that
+        // finds more is redone the exact way below.
+        const int64_t held = (int64_t)std::min(c->hit_out.cap / 60, c->hit_desc.cap / sizeof(int4));
+        const int64_t bound = c->last_hits + c->last_hits / 8 + 4096;
+        if (c->last_hits >= 0 && held >= bound && !getenv("WFA_NO_SPECULATE")) {
+            rp.cap = bound;
+            rp.n_dev = d_total;
+            {
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(launch_hit_runs(c->stream, rv0, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
+                                              c->rec_out_start.as<int64_t>(), c->hit_desc.as<int4>(), rp));
+                if ((rc = t.end("k_hit_runs"))) return rc;
+            }
+            {
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pv0, rv0, sp0, rp, c->hit_desc.as<int4>(), bound,
+                                                   c->hit_out.as<uint8_t>()));
+                if ((rc = t.end("k_hit_rows_grp"))) return rc;
+            }
+            {
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pv0, rv0, sp0, rp,
+                                                      c->hit_desc.as<int4>(), bound, true, c->hit_out.as<uint8_t>()));
+                if ((rc = t.end("k_hit_rows_literal"))) return rc;
+            }
+            WFA_HIP_CHECK(hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (total <= bound) {
+                c->last_hits = total;
+                c->n_hits = total;
+                *n_hits = total;
+                return WFA_OK;
+            }
+            rp.cap = 0;
+            rp.n_dev = nullptr;
+        }
+        WFA_HIP_CHECK(hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->last_hits = total;
+        // first pass on this context (or a pass that outgrew the guess): size the row buffers with head room so
+        // that the next pass can take the speculative tail
+        const int64_t want = total + total / 8 + 4096;
+        if ((rc = c->hit_out.ensure((size_t)want * 60))) return rc;
+        if ((rc = c->hit_desc.ensure((size_t)want * sizeof(int4)))) return rc;
         {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_hit_runs(c->stream, rv0, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
@@ -351,6 +395,9 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     for (DevBuf& b : c->ht) b.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    (void)profile_flush(c);
+    for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
+    c->prof_free.clear();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -914,18 +961,22 @@ int wfa_width_integral(wfa_ctx* c, int source, double q_low, double q_high, doub
 
 int wfa_profile_enable(wfa_ctx* c, int on) {
     if (!c) return fail(WFA_E_INVALID, "null context");
+    if (!on) (void)profile_flush(c);
     c->prof_on = on != 0;
     return WFA_OK;
 }
 
 int wfa_profile_reset(wfa_ctx* c) {
     if (!c) return fail(WFA_E_INVALID, "null context");
+    (void)profile_flush(c);
     c->prof.clear();
     return WFA_OK;
 }
 
 int wfa_profile_get(wfa_ctx* c, int idx, char* name, size_t name_len, double* total_ms, int64_t* launches) {
     if (!c) return fail(WFA_E_INVALID, "null context");
+    (void)hipSetDevice(c->device);
+    (void)profile_flush(c);
     if (idx < 0 || idx >= (int)c->prof.size()) return WFA_E_INVALID;
     const ProfEntry& e = c->prof[idx];
     if (name && name_len) snprintf(name, name_len, "%s", e.name.c_str());

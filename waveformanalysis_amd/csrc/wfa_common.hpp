@@ -101,6 +101,7 @@ struct wfa_ctx {
     wfa::DevBuf bitmap;         // 1 bit per sample, per-record regions (bm_off)
     wfa::DevBuf hit_desc;       // int4 (record, start, end, k) per hit
     int64_t n_hits = -1;
+    int64_t last_hits = -1;  // hits of the previous fast-path pass on this context (sizes the speculative tail)
 
     wfa::DevBuf out_rows;  // per-record feature rows
     wfa::DevBuf peak_out;  // HIT_DTYPE rows of the last find_peaks pass
@@ -116,9 +117,17 @@ struct wfa_ctx {
     int64_t* ht_perm = nullptr;
     wfa::DevBuf bw_scratch;  // float64 forward pass of sosfiltfilt, [sample][record-in-batch]
 
-    // profiling
+    // profiling: HIP events around every launch on the context's stream.  The pairs are only recorded while the
+    // work runs and resolved (hipEventElapsedTime) when the report is read, so timing adds no host round trip
+    // between the kernels of a pass.
     bool prof_on = false;
     std::vector<wfa::ProfEntry> prof;
+    struct PendingEvent {
+        hipEvent_t e0, e1;
+        std::string name;
+    };
+    std::vector<PendingEvent> prof_pending;
+    std::vector<hipEvent_t> prof_free;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // rccl (opaque, owned by wfa_rccl.hip)
@@ -128,27 +137,52 @@ struct wfa_ctx {
 
 namespace wfa {
 
-// RAII-less launch timer: call begin() before the launch and end(name) after it.
+// Launch timer: constructed before the launch(es), end(name) after them.
 struct LaunchTimer {
     wfa_ctx* c;
+    hipEvent_t e0 = nullptr;
+    static hipEvent_t take(wfa_ctx* c) {
+        if (!c->prof_free.empty()) {
+            hipEvent_t e = c->prof_free.back();
+            c->prof_free.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
     explicit LaunchTimer(wfa_ctx* ctx) : c(ctx) {
-        if (c->prof_on) (void)hipEventRecord(c->ev0, c->stream);
+        if (!c->prof_on) return;
+        e0 = take(c);
+        if (e0) (void)hipEventRecord(e0, c->stream);
     }
     int end(const char* name) {
-        if (!c->prof_on) return WFA_OK;
-        WFA_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
-        WFA_HIP_CHECK(hipEventSynchronize(c->ev1));
-        float ms = 0.f;
-        WFA_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        for (auto& e : c->prof)
-            if (e.name == name) {
-                e.total_ms += ms;
-                e.launches += 1;
-                return WFA_OK;
-            }
-        c->prof.push_back({name, (double)ms, 1});
+        if (!c->prof_on || !e0) return WFA_OK;
+        hipEvent_t e1 = take(c);
+        if (!e1) { c->prof_free.push_back(e0); e0 = nullptr; return WFA_OK; }
+        WFA_HIP_CHECK(hipEventRecord(e1, c->stream));
+        c->prof_pending.push_back({e0, e1, name});
+        e0 = nullptr;
         return WFA_OK;
     }
 };
+
+// resolve the recorded pairs into the per-name totals (blocks until the last recorded event has completed)
+inline int profile_flush(wfa_ctx* c) {
+    for (auto& p : c->prof_pending) {
+        float ms = 0.f;
+        hipError_t err = hipEventSynchronize(p.e1);
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, p.e0, p.e1);
+        c->prof_free.push_back(p.e0);
+        c->prof_free.push_back(p.e1);
+        if (err != hipSuccess) continue;
+        bool found = false;
+        for (auto& e : c->prof)
+            if (e.name == p.name) { e.total_ms += ms; e.launches += 1; found = true; break; }
+        if (!found) c->prof.push_back({p.name, (double)ms, 1});
+    }
+    c->prof_pending.clear();
+    return WFA_OK;
+}
 
 }  // namespace wfa

@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
     int4* __restrict__ out = desc + out_start[r];
     auto emit = [&](int k, int start, int end) {
         const bool fast = rp.fast_halo > 0 && L >= 2 * rp.fast_halo + 1;  // record filtered with the full window
-        out[k] = make_int4((int)r, start, end, fast ? 0 : 1);
+        if (rp.cap == 0 || out_start[r] + k < rp.cap) out[k] = make_int4((int)r, start, end, fast ? 0 : 1);
     };
     int k = 0;
     int run_start = -1;  // >= 0 while inside a run
@@ -1633,6 +1633,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecV
                                                              const int4* __restrict__ desc, int64_t n_hits,
                                                              int only_flagged, uint8_t* __restrict__ out) {
     const int64_t h = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (rp.n_dev && *rp.n_dev < n_hits) n_hits = *rp.n_dev;
     if (h >= n_hits) return;
     const int4 d = desc[h];
     if (only_flagged && d.w == 0) return;
@@ -1687,6 +1688,8 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     const int q = threadIdx.x & 7;
     const int grp = threadIdx.x >> 3;
     const int64_t h_base = (int64_t)blockIdx.x * kRowsHits;
+    if (rp.n_dev && *rp.n_dev < n_hits) n_hits = *rp.n_dev;
+    if (h_base >= n_hits) return;  // whole block beyond the rows of this pass (uniform: before any barrier)
     {
         // window length of the hit in this group's slot (0 = nothing to do), then rank = position in
         // descending order (ties by slot), computed by the group's 8 lanes over 16 slots each

@@ -84,6 +84,10 @@ struct SpanParams {
 struct RowParams {
     int32_t le, re, max_len;
     int32_t fast_halo;  // SG half window when the integer row kernel may be used, else 0
+    // speculative launch (no host round trip for the hit count): the kernels are launched for `cap` rows, the row
+    // count of this pass is read from `n_dev` on the device, nothing is written at or beyond row `cap`
+    int64_t cap = 0;
+    const int64_t* n_dev = nullptr;
 };
 
 // find_peaks-based hit detector (k_find_peaks): scalar lower bounds only, as the reference plugin passes them
