@@ -1524,8 +1524,10 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
                                                      int4* __restrict__ desc, RowParams rp) {
     // The mask regions of a block's 256 records are contiguous (bm_off is cumulative): stage them in
     // LDS with coalesced 16-byte loads when they fit, so the per-lane bit scan never waits on HBM.
-    constexpr int kStageBytes = 48 * 1024;
-    __shared__ uint4 s_bm[kStageBytes / 16];
+    // dynamic LDS sized by the launcher to the largest block region (<= 48 KiB): a fixed 48 KiB buffer allowed 3
+    // blocks per CU, the 28 KiB an 800-sample run needs allow 5
+    extern __shared__ uint4 s_bm[];
+    const int kStageBytes = rp.stage_bytes;
     const int64_t r_first = (int64_t)blockIdx.x * kBlock;
     const int64_t r_last = r_first + kBlock < rec.R ? r_first + kBlock : rec.R;  // exclusive
     const int64_t b_first = rec.bm_off[r_first];
@@ -3114,7 +3116,7 @@ hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bi
                            const int64_t* out_start, int4* desc, const RowParams& rp) {
     if (rec.R == 0) return hipSuccess;
     const unsigned grid = (unsigned)((rec.R + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kBlock), 0, st, rec, bitmap, nhits, out_start, desc, rp);
+    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kBlock), (size_t)rp.stage_bytes, st, rec, bitmap, nhits, out_start, desc, rp);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct SpanParams {
 struct RowParams {
     int32_t le, re, max_len;
     int32_t fast_halo;  // SG half window when the integer row kernel may be used, else 0
+    int32_t stage_bytes = 48 * 1024;  // LDS staging of k_hit_runs: mask bytes of 256 consecutive records (0 = none)
     // speculative launch (no host round trip for the hit count): the kernels are launched for `cap` rows, the row
     // count of this pass is read from `n_dev` on the device, nothing is written at or beyond row `cap`
     int64_t cap = 0;
