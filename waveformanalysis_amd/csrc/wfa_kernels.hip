@@ -3061,7 +3061,10 @@ bool sg_mask_span16_supported(const SgParams& sg, int L) {
 hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
     int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t resident = 256 * WFA_SPAN_WAVES;
+    // three rounds of the resident set: with exactly one round (persistent waves, spans dealt round-robin) the
+    // 19 531 spans of the 10^9-sample chunk give 4.77 spans per wave, i.e. the last round runs 77 % full; shorter
+    // blocks let the dispatcher even that out (grid x1 / x2 / x3 / x5 / x8: 0.695 / 0.677 / 0.662 / 0.677 / 0.678 ms)
+    const int64_t resident = 3 * 256 * WFA_SPAN_WAVES;
     if (g < 1) g = 1;
     if (g > resident) g = resident;
     const int grid = (int)g;
