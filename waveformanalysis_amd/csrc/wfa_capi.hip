@@ -198,9 +198,9 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         const int64_t* d_total = c->scan_blocks.as<int64_t>() + nb;
         RowParams rp{le, re, max_len, sp0.W / 2};
         {
-            // mask bytes of a block of 256 records (+16 for the aligned start), rounded up to 1 KiB
+            // mask bytes of one block's records (+16 for the aligned start), rounded up to 1 KiB
             const int64_t per_rec = ((int64_t)c->max_len + 7 + 63) / 64 * 8 + 8;
-            const int64_t need = (per_rec * 256 + 16 + 1023) / 1024 * 1024;
+            const int64_t need = (per_rec * hit_runs_block() + 16 + 1023) / 1024 * 1024;
             rp.stage_bytes = need <= 48 * 1024 ? (int32_t)need : 48 * 1024;
         }
         // Speculative tail: a pass usually finds about as many hits as the previous one on this context.  When the

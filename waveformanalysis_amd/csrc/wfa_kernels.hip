@@ -1518,7 +1518,11 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask_span_mfma(PoolView pool, Rec
 // ---- B1: runs of set bits of every record -> hit descriptors ----------------------------------------
 // desc = (record, start, end, flag); flag 0: record filtered with the full SG window (integer row
 // kernel), 1: literal float64 row kernel (short record / no integer plan).
-__global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t* __restrict__ bitmap,
+#ifndef WFA_RUNS_BLOCK
+#define WFA_RUNS_BLOCK 256
+#endif
+constexpr int kRunsBlock = WFA_RUNS_BLOCK;  // records (= lanes) per block of k_hit_runs
+__global__ __launch_bounds__(kRunsBlock) void k_hit_runs(RecView rec, const uint8_t* __restrict__ bitmap,
                                                      const int32_t* __restrict__ nhits,
                                                      const int64_t* __restrict__ out_start,
                                                      int4* __restrict__ desc, RowParams rp) {
@@ -1528,8 +1532,8 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
     // blocks per CU, the 28 KiB an 800-sample run needs allow 5
     extern __shared__ uint4 s_bm[];
     const int kStageBytes = rp.stage_bytes;
-    const int64_t r_first = (int64_t)blockIdx.x * kBlock;
-    const int64_t r_last = r_first + kBlock < rec.R ? r_first + kBlock : rec.R;  // exclusive
+    const int64_t r_first = (int64_t)blockIdx.x * kRunsBlock;
+    const int64_t r_last = r_first + kRunsBlock < rec.R ? r_first + kRunsBlock : rec.R;  // exclusive
     const int64_t b_first = rec.bm_off[r_first];
     const int64_t b_last = rec.bm_off[r_last - 1] + (((int64_t)rec.len[r_last - 1] + 7 + 63) / 64 * 8 + 8);
     const bool staged = (b_last - b_first) <= kStageBytes;  // b_first is a multiple of 8, regions are 8-byte multiples
@@ -1537,7 +1541,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_runs(RecView rec, const uint8_t*
         const int64_t a_first = b_first & ~15ll;  // 16-byte aligned start (bitmap buffer is 256-byte aligned)
         const int n16 = (int)((b_last - a_first + 15) >> 4);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(bitmap + a_first);
-        for (int k = threadIdx.x; k < n16 && k < kStageBytes / 16; k += kBlock) s_bm[k] = src[k];
+        for (int k = threadIdx.x; k < n16 && k < kStageBytes / 16; k += kRunsBlock) s_bm[k] = src[k];
         __syncthreads();
     }
     const int64_t r = r_first + threadIdx.x;
@@ -2978,6 +2982,8 @@ hipError_t launch_peak_rows(hipStream_t st, int source, const PoolView& pool, co
     return hipGetLastError();
 }
 
+int hit_runs_block() { return kRunsBlock; }
+
 bool sg_mask_supported(const SgParams& sg) {
     return sg.int_ok && sg.W >= 5 && sg.W <= 15 && (sg.W & 1);
 }
@@ -3124,8 +3130,8 @@ hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolVi
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
                            const int64_t* out_start, int4* desc, const RowParams& rp) {
     if (rec.R == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((rec.R + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kBlock), (size_t)rp.stage_bytes, st, rec, bitmap, nhits, out_start, desc, rp);
+    const unsigned grid = (unsigned)((rec.R + kRunsBlock - 1) / kRunsBlock);
+    hipLaunchKernelGGL(k_hit_runs, dim3(grid), dim3(kRunsBlock), (size_t)rp.stage_bytes, st, rec, bitmap, nhits, out_start, desc, rp);
     return hipGetLastError();
 }
 

@@ -149,6 +149,7 @@ hipError_t launch_peak_eval(hipStream_t st, int source, const PoolView& pool, co
 hipError_t launch_peak_rows(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
                             int64_t n_cand, const int64_t* cand_rec, const int32_t* cand_pos, const int32_t* accept,
                             const int64_t* row_start, const double* ips, uint8_t* out, int* err);
+int hit_runs_block();  // records per block of k_hit_runs (sizes its LDS staging)
 bool sg_mask_supported(const SgParams& sg);
 hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);
