@@ -154,7 +154,13 @@ int wfa_fused_baseline_filter_hits(wfa_ctx* ctx, int32_t bl_start, int32_t bl_en
  * threshold=None.  An empty minmax window fails with numpy's "zero-size array ..." message (WFA_E_INVALID). */
 #define WFA_HEIGHT_MINMAX 0
 #define WFA_HEIGHT_DIFF 1
-int wfa_find_peaks_count(wfa_ctx* ctx, int source, int use_derivative, double height, int has_threshold,
+/* signal_mode: WFA_PEAK_SIGNAL_RECORDS = records branch (signal = -rv.signals(id): float32 (w - baseline), sign by
+ * polarity; detection on diff(signal) or signal).  WFA_PEAK_SIGNAL_ROWS = dense st_waveforms / filtered_waveforms
+ * branch (peak_finding.py:316-378): the stored samples are the waveform, pulses are negative-going (detection on
+ * -diff(row) in the row's dtype or float64 baseline - row), the height is measured on the row itself. */
+#define WFA_PEAK_SIGNAL_RECORDS 0
+#define WFA_PEAK_SIGNAL_ROWS 1
+int wfa_find_peaks_count(wfa_ctx* ctx, int source, int signal_mode, int use_derivative, double height, int has_threshold,
                          double threshold, int32_t distance, double prominence, double width, int height_method,
                          int32_t height_window_extension, int64_t* n_peaks);
 int wfa_find_peaks_fill(wfa_ctx* ctx, void* out_rows, int64_t n_peaks);

@@ -551,6 +551,101 @@ def basic_features_dense(data: np.ndarray, *, height_range=(40, 90), area_range=
     return out
 
 
+def threshold_hits_dense(data: np.ndarray, record_lengths: np.ndarray, *, threshold=10.0, thresholds=None,
+                         left_extension=2, right_extension=2) -> np.ndarray:
+    """hit_finder.py:179-255 dense branch: the WHOLE row is searched (no valid mask), `record_lengths` (the
+    records/wave_pool lengths of the same record_ids, hit_finder.py:257-286) only clamp the edges."""
+    if len(data) == 0:
+        return np.zeros(0, dtype=THRESHOLD_HIT_DTYPE)
+    names = data.dtype.names or ()
+    n = len(data)
+    waves = np.asarray(data["wave"]).astype(np.float64, copy=False)
+    baselines = data["baseline"].astype(np.float64) if "baseline" in names else waves.mean(axis=1, dtype=np.float64)
+    thr = (np.full(n, float(threshold), dtype=np.float64) if thresholds is None
+           else np.asarray(thresholds, dtype=np.float64))
+    positive = positive_mask_from_polarity(data)
+    b2 = baselines[:, np.newaxis]
+    signal = np.where(positive[:, np.newaxis], waves - b2, b2 - waves)
+    col = lambda f, t, d: data[f].astype(t) if f in names else d  # noqa: E731
+    return hits_from_signal_matrix(
+        signal, thr, col("timestamp", np.int64, np.zeros(n, np.int64)), col("board", np.int16, np.zeros(n, np.int16)),
+        col("channel", np.int16, np.zeros(n, np.int16)), col("record_id", np.int64, np.arange(n, dtype=np.int64)),
+        max(0, int(left_extension)), max(0, int(right_extension)), data["dt"].astype(np.int32), None,
+        np.asarray(record_lengths, dtype=np.int64))
+
+
+def width_integral_dense(data: np.ndarray, *, q_low=0.10, q_high=0.90, dt=None, sampling_rate=0.5) -> np.ndarray:
+    """waveform_width_integral.py:139-231 dense branch: float64 of the row minus the float64 baseline, sign from
+    the literal "positive" only."""
+    if dt is None:
+        dt = 1.0 / float(sampling_rate)
+    names = data.dtype.names or ()
+    rows = []
+    for idx in range(len(data)):
+        wave = data[idx]["wave"]
+        baseline = float(data[idx]["baseline"])
+        pol = str(data[idx]["polarity"]) if "polarity" in names else "unknown"
+        raw_signal = wave.astype(np.float64, copy=False) - baseline
+        signal = raw_signal if pol == "positive" else -raw_signal
+        x = np.maximum(signal, 0.0)
+        q_total = float(np.sum(x))
+        if q_total <= 0 or not np.isfinite(q_total):
+            lo = hi = w = 0.0
+        else:
+            cumsum = np.cumsum(x)
+            lo_i = int(np.searchsorted(cumsum, q_low * q_total, side="left"))
+            hi_i = int(np.searchsorted(cumsum, q_high * q_total, side="left"))
+            lo, hi, w = float(lo_i), float(hi_i), float(max(hi_i - lo_i, 0))
+        rows.append((float(lo * dt), float(hi * dt), float(w * dt), lo, hi, w, q_total, int(data[idx]["timestamp"]),
+                     int(data[idx]["board"]) if "board" in names else 0,
+                     int(data[idx]["channel"]) if "channel" in names else 0, idx))
+    if rows:
+        return np.array(rows, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)
+    return np.zeros(0, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE)
+
+
+def find_peak_hits_dense(data: np.ndarray, *, use_derivative=True, height=30.0, distance=2, prominence=0.7, width=4,
+                         threshold=None, height_method="minmax", height_window_extension=4) -> np.ndarray:
+    """peak_finding.py:316-378 + 446-614 dense branch: the row itself (int16 or float32, truncated to
+    event_length) is the waveform, pulses are negative-going (`-np.diff(w)` in the row's dtype, or
+    `baseline - w`), the height is taken on the row."""
+    if height_method not in ("minmax", "diff"):
+        raise ValueError(f"不支持的峰高计算方法: {height_method}")
+    names = data.dtype.names or ()
+    rows = []
+    for idx in range(len(data)):
+        row = data[idx]
+        w = row["wave"]
+        ev = int(row["event_length"]) if "event_length" in names else len(w)
+        if 0 < ev < len(w):
+            w = w[:ev]
+        baseline = row["baseline"] if "baseline" in names else None
+        if use_derivative:
+            det = -np.diff(w)
+        elif baseline is not None:
+            det = baseline - w
+        else:
+            det = np.mean(w) - w
+        det = np.asarray(det, dtype=np.float64)
+        peaks, l_ips, r_ips = find_peaks_staged(det, float(height), threshold, int(distance), float(prominence),
+                                                int(width))
+        dt_ns = int(row["dt"])
+        for pos, l_ip, r_ip in zip(peaks, l_ips, r_ips):
+            start_idx = max(0, int(np.round(l_ip)))
+            end_idx = min(len(w) - 1, int(np.round(r_ip)))
+            if height_method == "minmax":
+                ext = max(0, int(height_window_extension))
+                w0, w1 = max(0, start_idx - ext), min(len(w), end_idx + ext)
+                ph = np.max(w[w0:w1]) - np.min(w[w0:w1])
+            else:
+                ph = np.sum(np.diff(-w)[start_idx:end_idx]) if end_idx > start_idx else 0.0
+            ts = int(row["timestamp"] + pos * (dt_ns * 1e3))
+            rows.append((int(pos), float(ph), 0.0, float(l_ip), float(r_ip), dt_ns, ts,
+                         int(row["board"]) if "board" in names else 0, int(row["channel"]) if "channel" in names else 0,
+                         int(row["record_id"]) if "record_id" in names else idx))
+    return np.array(rows, dtype=HIT_DTYPE) if rows else np.zeros(0, dtype=HIT_DTYPE)
+
+
 def _first_crossing(seg: np.ndarray, level, rising: bool, interpolate: bool):
     """waveform_width.py:332-374: first sample at/over (rising) or at/under (falling) `level`, refined by the
     straight line through its left neighbour.  Keeps numpy's scalar types exactly as the reference's

@@ -246,6 +246,52 @@ def dense_case(name, records, pool, *, filter_cc, width_cfgs, s1s2_cfgs):
           f"-> {os.path.getsize(path)} B")
 
 
+def densehit_case(name, records, pool, *, hit_cfgs, wi_cfgs, peak_cfgs):
+    """Dense (wave_source auto / st_waveforms / filtered_waveforms) branches of ThresholdHitPlugin
+    (hit_finder.py:179-286), WaveformWidthIntegralPlugin (waveform_width_integral.py:139-231) and HitFinderPlugin
+    (peak_finding.py:316-378).  `st_pad` has rows whose event_length is shorter than the row."""
+    if not name.startswith(ONLY):
+        return
+    from unittest.mock import patch
+
+    from waveform_analysis.core.plugins.builtin.cpu.filtering import FilteredWaveformsPlugin
+    from waveform_analysis.core.plugins.builtin.cpu.peak_finding import HitFinderPlugin
+    from waveform_analysis.core.processing.records_builder import build_records_from_st_waveforms
+
+    st = st_from_records(records, pool)
+    st_pad = st.copy()
+    st_pad["event_length"][1::3] = 500
+    out = {"st_waveforms": st, "st_pad": st_pad}
+    filt = FilteredWaveformsPlugin().compute(Ctx({"max_workers": 1}, {"st_waveforms": st}), "run")
+    out["filtered_waveforms"] = filt
+    filt_pad = filt.copy()
+    filt_pad["event_length"][1::3] = 500
+    sources = {"st": (st, {}), "filt": (filt, {"use_filtered": True}), "pad": (st_pad, {}),
+               "filtpad": (filt_pad, {"wave_source": "filtered_waveforms"})}
+    for tag, (arr, base) in sources.items():
+        data = {"st_waveforms": arr, "filtered_waveforms": arr}
+        bundle = build_records_from_st_waveforms(arr, default_dt_ns=4)
+        out[f"reclen_{tag}"] = bundle.records["event_length"].astype(np.int64)
+        out[f"recid_{tag}"] = bundle.records["record_id"].astype(np.int64)
+        with patch("waveform_analysis.core.plugins.builtin.cpu.records.get_records_bundle", return_value=bundle):
+            for k, cfg in enumerate(hit_cfgs):
+                out[f"hits_{tag}_{k}"] = ThresholdHitPlugin().compute(Ctx({**base, **cfg}, data), "run")
+        if tag in ("st", "filt"):
+            for k, cfg in enumerate(wi_cfgs):
+                out[f"wi_{tag}_{k}"] = WaveformWidthIntegralPlugin().compute(Ctx({**base, **cfg}, data), "run")
+        for k, cfg in enumerate(peak_cfgs):
+            if tag in ("st", "pad") and cfg.get("distance", 2) > 2:
+                continue  # integer rows: equal-height candidates, scipy's distance step depends on an unstable argsort
+            full = {"use_filtered": False, **base, **cfg}
+            out[f"peak_{tag}_{k}"] = HitFinderPlugin().compute(Ctx(full, data), "run")
+    opts = {"hit": hit_cfgs, "wi": wi_cfgs, "peak": peak_cfgs}
+    out["options_json"] = np.frombuffer(json.dumps(opts).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: " + ", ".join(f"{k}={len(v)}" for k, v in out.items() if k.startswith(("hits_", "peak_"))) +
+          f" -> {os.path.getsize(path)} B")
+
+
 def crafted_hits(seed, n, n_records=60):
     """THRESHOLD_HIT_DTYPE rows whose records abut in time, so chains cross record boundaries; few distinct
     heights (anchor ties), two sample intervals, unsorted input order."""
@@ -703,6 +749,17 @@ def main():
                            "s2_width_range": (20.0, None), "s2_height_range": (50.0, None),
                            "conflict_policy": "prefer_s2"},
                           {"s1_height_range": (10.0, 1e9), "s2_area_range": (-1e9, 1e9), "conflict_policy": "prefer_s1"}])
+
+    densehit_case("densehit_v1725", rmix, pmix,
+                  hit_cfgs=[{}, {"threshold": 25.0, "left_extension": 5, "right_extension": 0,
+                                 "channel_config": {"0:3": {"threshold": 8.0}, "0:7": {"threshold": 300.0}}}],
+                  wi_cfgs=[{}, {"q_low": 0.25, "q_high": 0.6, "dt": 4.0}],
+                  peak_cfgs=[{}, {"use_derivative": False, "height": 40.0, "width": 3, "prominence": 5.0},
+                             {"height": 8.0, "distance": 6, "prominence": 0.5, "width": 1, "height_window_extension": 0},
+                             {"height": 12.0, "distance": 1, "prominence": 2.0, "width": 2, "threshold": 1.0},
+                             {"height_method": "diff", "height": 20.0, "width": 2},
+                             {"use_derivative": False, "height": 25.0, "width": 2, "prominence": 3.0,
+                              "height_method": "diff"}])
 
     # event grouping of threshold hits from a 16-channel run and from a 256-channel run
     for preset, cfg, nrec in (("v1725", 8, 400), ("vx2730", 9, 600)):

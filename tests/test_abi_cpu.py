@@ -101,18 +101,26 @@ def test_plugin_contract_attributes():
     ww = [p for p in hip_default() if p.provides == "waveform_width"][0]
     assert ww.resolve_depends_on(SimpleContext({"use_filtered": True})) == ["hit", "filtered_waveforms"]
     hit = [p for p in hip_default() if p.provides == "hit_threshold"][0]
-    ctx = SimpleContext({"use_filtered": True})
+    assert hit.resolve_depends_on(SimpleContext({})) == ["st_waveforms"]  # reference default: wave_source="auto"
+    assert hit.resolve_depends_on(SimpleContext({"use_filtered": True})) == ["filtered_waveforms"]
+    ctx = SimpleContext({"wave_source": "records", "use_filtered": True})
     assert hit.resolve_depends_on(ctx) == ["records", "wave_pool_filtered"]
-    ctx = SimpleContext({"use_filtered": True, "fuse_filter": True})
+    ctx = SimpleContext({"wave_source": "records", "use_filtered": True, "fuse_filter": True})
     assert hit.resolve_depends_on(ctx) == ["records", "wave_pool"]
-    with pytest.raises(ValueError, match="wave_source"):
-        hit.resolve_depends_on(SimpleContext({"wave_source": "st_waveforms"}))
+    assert hit.resolve_depends_on(SimpleContext({"wave_source": "st_waveforms"})) == ["st_waveforms"]
+    with pytest.raises(ValueError, match="Invalid wave_source"):
+        hit.resolve_depends_on(SimpleContext({"wave_source": "bogus"}))
+    for name in ("hit", "waveform_width_integral"):
+        p = [q for q in hip_default() if q.provides == name][0]
+        assert p.resolve_depends_on(SimpleContext({"use_filtered": False})) == ["st_waveforms"]
+        assert p.resolve_depends_on(SimpleContext({"wave_source": "records", "use_filtered": False})) == ["records", "wave_pool"]
 
 
 def test_empty_inputs_need_no_device():
     from waveformanalysis_amd.dtypes import RECORDS_DTYPE, THRESHOLD_HIT_DTYPE
 
     hit = [p for p in hip_default() if p.provides == "hit_threshold"][0]
-    ctx = SimpleContext({}, {"records": np.zeros(0, dtype=RECORDS_DTYPE), "wave_pool": np.zeros(0, dtype=np.uint16)})
+    ctx = SimpleContext({"wave_source": "records"},
+                        {"records": np.zeros(0, dtype=RECORDS_DTYPE), "wave_pool": np.zeros(0, dtype=np.uint16)})
     out = hit.compute(ctx, "run")
     assert out.dtype == THRESHOLD_HIT_DTYPE and len(out) == 0

@@ -150,7 +150,7 @@ def test_plugins_drop_in_chain():
     case = G.load_case("v1725_channel_cfg")
     opt = case["options"]
     ctx = SimpleContext(
-        {"hit_threshold": {**opt["hit"], "use_filtered": True}, "basic_features": {**opt["bf"], "wave_source": "records"}},
+        {"wave_source": "records", "hit_threshold": {**opt["hit"], "use_filtered": True}, "basic_features": opt["bf"]},
         {"records": case["records"], "wave_pool": case["wave_pool"]},
         plugins=[HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
                  HipWaveformWidthIntegralPlugin()],
@@ -160,7 +160,8 @@ def test_plugins_drop_in_chain():
     G.assert_struct_equal(ctx.get_data("run", "basic_features"), case["bf_raw"])
     G.assert_struct_equal(ctx.get_data("run", "waveform_width_integral"), case["wi_raw"])
     # fused variant gives the same hits without materialising the filtered pool
-    ctx2 = SimpleContext({"hit_threshold": {**opt["hit"], "use_filtered": True, "fuse_filter": True}},
+    ctx2 = SimpleContext({"wave_source": "records",
+                          "hit_threshold": {**opt["hit"], "use_filtered": True, "fuse_filter": True}},
                          {"records": case["records"], "wave_pool": case["wave_pool"]},
                          plugins=[HipWavePoolFilteredPlugin(), HipThresholdHitPlugin()])
     G.assert_struct_equal(ctx2.get_data("run", "hit_threshold"), case["hits_filt"], float_rtol=FLOAT_RTOL)
@@ -235,7 +236,7 @@ def test_streaming_chunks_with_device_pool():
     from waveformanalysis_amd.streaming import HipThresholdHitStream, records_to_chunks
 
     rec, pool = synth.make_run(3000, "v1725", cfg=32)
-    ctx = SimpleContext({}, {"records": rec, "wave_pool": pool})
+    ctx = SimpleContext({"wave_source": "records"}, {"records": rec, "wave_pool": pool})
     dp = DevicePool([0])
     try:
         for use_filtered in (False, True):
@@ -250,7 +251,7 @@ def test_streaming_chunks_with_device_pool():
             # processed twice and clipped away again, results arrive in input order
             rec2 = rec.copy()
             rec2["timestamp"][1500:] += 3 * 10**13
-            ctx2 = SimpleContext({}, {"records": rec2, "wave_pool": pool})
+            ctx2 = SimpleContext({"wave_source": "records"}, {"records": rec2, "wave_pool": pool})
             want2 = O.threshold_hits_chunked(rec2, O.filter_wave_pool_uniform(pool, 800) if use_filtered else pool)
             for cfg in ({"chunk_size": 400, "max_workers": 3}, {"chunk_size": 1000, "required_halo_ns": 30_000_000, "parallel": False}):
                 outs = list(plugin.compute(ctx2, "run", streaming_config=cfg))

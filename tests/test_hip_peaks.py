@@ -44,7 +44,7 @@ def test_session_matches_reference(sess, name):
 def test_plugin_matches_reference(name):
     case = G.load_peaks(name)
     for k, cfg in enumerate(case["configs"]):
-        ctx = SimpleContext({"hit": dict(cfg)},
+        ctx = SimpleContext({"wave_source": "records", "hit": dict(cfg)},
                             {"records": case["records"], "wave_pool": case["wave_pool"],
                              "wave_pool_filtered": case["wave_pool_filtered"]},
                             plugins=[HipHitFinderPlugin()])
@@ -54,7 +54,7 @@ def test_plugin_matches_reference(name):
 def test_plugin_chain_from_raw_pool():
     """hit <- wave_pool_filtered <- wave_pool, both stages on the GPU."""
     case = G.load_peaks("peaks_v1725")
-    ctx = SimpleContext({"hit": dict(case["configs"][0])},
+    ctx = SimpleContext({"wave_source": "records", "hit": dict(case["configs"][0])},
                         {"records": case["records"], "wave_pool": case["wave_pool"]},
                         plugins=[HipWavePoolFilteredPlugin(), HipHitFinderPlugin()])
     G.assert_struct_equal(ctx.get_data("run", "hit"), case["hit_0"])
@@ -113,7 +113,7 @@ def test_plugin_record_id_indirection_and_errors():
     rec = case["records"].copy()
     rec["record_id"] = rec["record_id"][::-1]
     data = {"records": rec, "wave_pool": case["wave_pool"], "wave_pool_filtered": case["wave_pool_filtered"]}
-    ctx = SimpleContext({"hit": dict(case["configs"][0])}, data, plugins=[HipHitFinderPlugin()])
+    ctx = SimpleContext({"wave_source": "records", "hit": dict(case["configs"][0])}, data, plugins=[HipHitFinderPlugin()])
     got = ctx.get_data("run", "hit")
     mixed = rec.copy()
     for f in ("wave_offset", "event_length", "baseline", "polarity"):
@@ -121,7 +121,8 @@ def test_plugin_record_id_indirection_and_errors():
     cfg = dict(case["configs"][0])
     cfg.pop("use_filtered", None)
     G.assert_struct_equal(got, O.find_peak_hits(mixed, case["wave_pool_filtered"], **cfg))
-    with pytest.raises(RuntimeError, match="wave_source"):
+    with pytest.raises(RuntimeError, match="requires 'st_waveforms'"):
         SimpleContext({"hit": {"wave_source": "st_waveforms"}}, data, plugins=[HipHitFinderPlugin()]).get_data("run", "hit")
     with pytest.raises(RuntimeError, match="峰高计算方法"):
-        SimpleContext({"hit": {"height_method": "nope"}}, data, plugins=[HipHitFinderPlugin()]).get_data("run", "hit")
+        SimpleContext({"hit": {"wave_source": "records", "height_method": "nope"}}, data,
+                      plugins=[HipHitFinderPlugin()]).get_data("run", "hit")

@@ -2167,6 +2167,7 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
     const float b32 = (float)baseline;
     const int pol = rec.pol[r];
     const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
+    const bool wpos = pol == WFA_POL_POSITIVE_WAVE;  // dense branch, polarity "positive" (waveform_width_integral.py:184-189)
     const int64_t c_lo = off >> 3, c_hi = (off + L - 1) >> 3;
 
     // x_i = max(signal_i, 0)   (waveform_width_integral.py:180-190)
@@ -2176,7 +2177,7 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
             const float dd = wfj - b32;
             sgl = (double)(pol == WFA_POL_POSITIVE ? dd : -dd);
         } else {
-            sgl = -(wdj - baseline);
+            sgl = wpos ? wdj - baseline : -(wdj - baseline);
         }
         return sgl > 0.0 ? sgl : 0.0;
     };
@@ -2448,26 +2449,46 @@ struct SignalAt {
     const uint16_t* xu;
     const float* xf;
     float b32;
+    double b64;
     bool positive;
     int use_derivative;
+    int rows;  // WFA_PEAK_SIGNAL_ROWS: dense branch, the stored samples are the waveform (negative-going pulses)
     int L, n;  // samples in the record, samples of the detection signal
+    // the waveform the height is measured on
     __device__ __forceinline__ double sig(int i) const {
         const float w = SRC == WFA_SRC_RAW ? (float)xu[i] : xf[i];
+        if (rows) return (double)w;
         const float d = w - b32;             // records_view.py:87-100 (float32)
         return (double)(positive ? d : -d);  // signal = -normalized
     }
-    __device__ __forceinline__ double det(int i) const {
-        return use_derivative ? sig(i + 1) - sig(i) : sig(i) - 0.0;
+    // value k of the detection signal from the float32 samples w0 = w[k], w1 = w[k + 1]  (peak_finding.py:490-510)
+    __device__ __forceinline__ double det_of(float w0, float w1) const {
+        if (rows) {
+            if (!use_derivative) return b64 - (double)w0;                   // np.float64 baseline - row
+            if (SRC == WFA_SRC_RAW) return -((double)w1 - (double)w0);      // -np.diff(int16 row): exact
+            return (double)(-(w1 - w0));                                    // -np.diff(float32 row): float32
+        }
+        const float d0 = w0 - b32;
+        const double s0 = (double)(positive ? d0 : -d0);
+        if (!use_derivative) return s0 - 0.0;
+        const float d1 = w1 - b32;
+        return (double)(positive ? d1 : -d1) - s0;
     }
-    __device__ __forceinline__ void bind(const PoolView& pool, const RecView& rec, int64_t r, int use_deriv) {
+    __device__ __forceinline__ float wave(int i) const { return SRC == WFA_SRC_RAW ? (float)xu[i] : xf[i]; }
+    __device__ __forceinline__ double det(int i) const {
+        return det_of(wave(i), use_derivative ? wave(i + 1) : 0.f);
+    }
+    __device__ __forceinline__ void bind(const PoolView& pool, const RecView& rec, int64_t r, const PeakParams& pp) {
         const int64_t off = rec.off[r];
         xu = pool.u16 ? pool.u16 + off : nullptr;
         xf = pool.f32 ? pool.f32 + off : nullptr;
-        b32 = (float)rec.baseline[r];
+        b64 = rec.baseline[r];
+        b32 = (float)b64;
         positive = rec.pol[r] == WFA_POL_POSITIVE;
-        use_derivative = use_deriv;
+        use_derivative = pp.use_derivative;
+        rows = pp.rows;
         L = rec.len[r];
-        n = use_deriv ? L - 1 : L;
+        n = use_derivative ? L - 1 : L;
     }
 };
 
@@ -2522,9 +2543,14 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
     double ph;
     if (pp.height_diff) {
         ph = 0.0;
-        if (end_idx > start_idx)
-            ph = np_pairwise_sum([&](int q) { return (-S.sig(q + 1)) - (-S.sig(q)); }, start_idx, end_idx - start_idx,
-                                 pw_scratch, kPeakBlock);
+        if (end_idx > start_idx) {
+            if (S.rows && SRC == WFA_SRC_F32)  // np.sum(np.diff(-row)) of a float32 row stays float32
+                ph = (double)np_pairwise_sum<float>([&](int q) { return (-S.xf[q + 1]) - (-S.xf[q]); }, start_idx,
+                                                    end_idx - start_idx, pw_scratch, kPeakBlock);
+            else
+                ph = np_pairwise_sum([&](int q) { return (-S.sig(q + 1)) - (-S.sig(q)); }, start_idx,
+                                     end_idx - start_idx, pw_scratch, kPeakBlock);
+        }
     } else {
         int w0 = start_idx - pp.ext, w1 = end_idx + pp.ext;
         if (w0 < 0) w0 = 0;
@@ -2536,7 +2562,7 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
             vmax = v > vmax ? v : vmax;
             vmin = v < vmin ? v : vmin;
         }
-        ph = vmax - vmin;
+        ph = S.rows && SRC == WFA_SRC_F32 ? (double)((float)vmax - (float)vmin) : vmax - vmin;
     }
     const int dt_ns = rec.dt[r];
     put_i64(row, 0, (int64_t)peak);
@@ -2559,7 +2585,8 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
     const int L = S.L;
     bool have = false;
     int c_start = 0;
-    double c_val = 0.0, x_prev = 0.0, s_prev = 0.0;
+    double c_val = 0.0, x_prev = 0.0;
+    float w_prev = 0.f;
     // one detection value per step; i is its index.  Samples arrive in aligned 16-byte chunks (8 uint16 or
     // 2 x 4 float32 per lane and load): a lane walks its own record, so single-sample loads would pull a whole
     // cache line per 2..4 useful bytes (measured 26 ms per 10^9 samples for the count pass alone).
@@ -2593,13 +2620,11 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
         for (int jj = 0; jj < 8; ++jj) {
             const int k = kb + jj;  // sample index in the record
             if (k < 0 || k >= L) continue;
-            const float d = wf[jj] - S.b32;
-            const double sk = (double)(S.positive ? d : -d);
             if (S.use_derivative) {
-                if (k >= 1) step(k - 1, sk - s_prev);
-                s_prev = sk;
+                if (k >= 1) step(k - 1, S.det_of(w_prev, wf[jj]));
+                w_prev = wf[jj];
             } else {
-                step(k, sk - 0.0);
+                step(k, S.det_of(wf[jj], 0.f));
             }
         }
     }
@@ -2618,7 +2643,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecVie
     const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (r >= rec.R) return;
     SignalAt<SRC> S;
-    S.bind(pool, rec, r, pp.use_derivative);
+    S.bind(pool, rec, r, pp);
     int n_out = 0;
     if (S.L > 0) {
         const int64_t base = FILL ? out_start[r] : 0;
@@ -2676,7 +2701,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_eval(PoolView pool, RecView
     double l_ip = 0.0, r_ip = 0.0;
     if (!state || state[k]) {
         SignalAt<SRC> S;
-        S.bind(pool, rec, cand_rec[k], pp.use_derivative);
+        S.bind(pool, rec, cand_rec[k], pp);
         ok = peak_passes(S, cand_pos[k], pp, l_ip, r_ip) ? 1 : 0;
     }
     accept[k] = ok;
@@ -2699,7 +2724,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_rows(PoolView pool, RecView
     if (k >= n_cand || !accept[k]) return;
     const int64_t r = cand_rec[k];
     SignalAt<SRC> S;
-    S.bind(pool, rec, r, pp.use_derivative);
+    S.bind(pool, rec, r, pp);
     write_peak_row(S, rec, r, cand_pos[k], ips[2 * k], ips[2 * k + 1], pp,
                    reinterpret_cast<uint32_t*>(out + row_start[k] * 48), err, &s_pw[0][threadIdx.x]);
 }

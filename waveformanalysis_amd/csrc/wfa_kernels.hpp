@@ -102,6 +102,7 @@ struct PeakParams {
     double wmin;
     int ext;
     int height_diff;  // 1: height_method 'diff', 0: 'minmax'
+    int rows;         // 1: WFA_PEAK_SIGNAL_ROWS (dense branch)
 };
 
 struct FeatParams {

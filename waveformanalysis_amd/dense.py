@@ -52,17 +52,28 @@ def dense_pool(waveform_data: np.ndarray, what: str = "st_waveforms") -> tuple[n
     raise ValueError(f"{what}['wave'] must be int16 or float32, got {wave.dtype}")
 
 
-def dense_records(waveform_data: np.ndarray, row_length: int) -> np.ndarray:
-    """Per-row records for the row-major pool of `dense_pool` (whole rows, as the dense branches read them)."""
+def dense_records(waveform_data: np.ndarray, row_length: int, *, keep_record_id: bool = False,
+                  truncate_to_event_length: bool = False) -> np.ndarray:
+    """Per-row records for the row-major pool of `dense_pool` (whole rows, as the dense branches read them).
+
+    keep_record_id: carry the array's own record_id (the hit tables report it); otherwise rows are numbered.
+    truncate_to_event_length: rows with 0 < event_length < row length are cut there (peak_finding.py:336-343)."""
     n = len(waveform_data)
     names = waveform_data.dtype.names or ()
     rec = np.zeros(n, dtype=DENSE_RECORD_DTYPE)
     for name, default in (("timestamp", 0), ("board", 0), ("channel", 0), ("baseline", np.nan), ("dt", 1)):
         rec[name] = waveform_data[name] if name in names else default
     rec["polarity"] = waveform_data["polarity"] if "polarity" in names else "negative"
-    rec["record_id"] = np.arange(n, dtype=np.int64)  # kernels address rows by position
+    if keep_record_id and "record_id" in names:
+        rec["record_id"] = waveform_data["record_id"]
+    else:
+        rec["record_id"] = np.arange(n, dtype=np.int64)  # kernels address rows by position
     rec["wave_offset"] = np.arange(n, dtype=np.int64) * int(row_length)
     rec["event_length"] = int(row_length)
+    if truncate_to_event_length and "event_length" in names:
+        ev = np.asarray(waveform_data["event_length"], dtype=np.int64)
+        cut = (ev > 0) & (ev < int(row_length))
+        rec["event_length"][cut] = ev[cut]
     return rec
 
 

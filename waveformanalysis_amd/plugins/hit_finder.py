@@ -13,6 +13,7 @@ from typing import Any
 
 import numpy as np
 
+from .. import dense
 from ..dtypes import HIT_DTYPE
 from ..plugin_api import Option, Plugin
 from . import _common as K
@@ -30,7 +31,8 @@ class HipHitFinderPlugin(Plugin):
 
     options = {
         "use_filtered": Option(default=True, type=bool, help="detect on wave_pool_filtered"),
-        "wave_source": Option(default=K.WAVE_SOURCE_RECORDS, type=str, help="must be 'records'"),
+        "wave_source": Option(default=K.WAVE_SOURCE_AUTO, type=str,
+                              help="auto|records|st_waveforms|filtered_waveforms"),
         "use_derivative": Option(default=True, type=bool, help="detect on the first difference"),
         "height": Option(default=30.0, type=float, help="minimum peak height"),
         "distance": Option(default=2, type=int, help="minimum distance between peaks (samples)"),
@@ -48,7 +50,7 @@ class HipHitFinderPlugin(Plugin):
     }
 
     def resolve_depends_on(self, context: Any, run_id: str | None = None) -> list[str]:
-        deps, _pool = K.records_dependencies(context, self)
+        _kind, deps, _name = K.resolve_wave_input(context, self)
         return deps
 
     def compute(self, context: Any, run_id: str, **_kwargs) -> np.ndarray:
@@ -61,14 +63,19 @@ class HipHitFinderPlugin(Plugin):
         height_method = str(context.get_config(self, "height_method"))
         ext = int(context.get_config(self, "height_window_extension"))
         explicit_dt = K.resolve_dt_config(context, self, deprecated_keys=("sampling_interval_ns", "dt_ns"))
-        _deps, pool_name = K.records_dependencies(context, self)
+        kind, _deps, pool_name = K.resolve_wave_input(context, self)
+        if threshold is not None and not np.isscalar(threshold):
+            raise ValueError("hit (HIP backend) takes a scalar threshold (a lower bound), or None")
+        peak_kw = dict(use_derivative=use_derivative, height=height, distance=distance, prominence=prominence,
+                       width=width, threshold=None if threshold is None else float(threshold),
+                       height_method=height_method, height_window_extension=ext)
+        if kind == "dense":
+            return self._compute_dense(context, run_id, pool_name, explicit_dt, peak_kw)
         records, pool = K.load_records_input(context, self, run_id, pool_name)
         if len(records) == 0:
             return np.zeros(0, dtype=HIT_DTYPE)
         if height_method not in ("minmax", "diff"):
             raise ValueError(f"不支持的峰高计算方法: {height_method}")  # peak_finding.py:612
-        if threshold is not None and not np.isscalar(threshold):
-            raise ValueError("hit (HIP backend) takes a scalar threshold (a lower bound), or None")
 
         names = records.dtype.names or ()
         if "dt" in names:
@@ -93,11 +100,31 @@ class HipHitFinderPlugin(Plugin):
             source = K.SRC_RAW
         sess = K.resident_session(context, pool)
         sess.upload_records(rec, np.zeros(len(rec), dtype=np.float64))
-        return sess.find_peaks(source, use_derivative=use_derivative, height=height, distance=distance,
-                               prominence=prominence, width=width,
-                               threshold=None if threshold is None else float(threshold),
-                               height_method=height_method,
-                               height_window_extension=ext)
+        return sess.find_peaks(source, **peak_kw)
+
+    def _compute_dense(self, context, run_id, data_name, explicit_dt, peak_kw) -> np.ndarray:
+        """peak_finding.py:316-378: the row (cut at event_length) is the waveform, pulses are negative-going."""
+        data = K.load_dense_input(context, self, run_id, data_name)
+        if len(data) == 0:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        if peak_kw["height_method"] not in ("minmax", "diff"):
+            raise ValueError(f"不支持的峰高计算方法: {peak_kw['height_method']}")
+        names = data.dtype.names or ()
+        if "dt" not in names and explicit_dt is None:
+            raise ValueError("[hit] st_waveforms is missing required field 'dt'; provide explicit config 'dt'.")
+        dt_values = np.asarray(data["dt"], dtype=np.int64) if "dt" in names else np.full(len(data), int(explicit_dt), np.int64)
+        if np.any(dt_values <= 0):
+            raise ValueError("[hit] dt must be > 0")
+        if np.any(dt_values > np.iinfo(np.int32).max):
+            raise ValueError(f"[hit] dt exceeds int32 range: {int(dt_values.max())}")
+        if "baseline" not in names and not peak_kw["use_derivative"]:
+            raise ValueError(f"hit (HIP backend) needs a 'baseline' field on {data_name} when use_derivative=False")
+        pool, source, L = dense.dense_pool(data, data_name)
+        rec = dense.dense_records(data, L, keep_record_id=True, truncate_to_event_length=True)
+        rec["dt"] = dt_values
+        sess = K.resident_session(context, pool)
+        sess.upload_records(rec, np.zeros(len(rec), dtype=np.float64))
+        return sess.find_peaks(source, dense_rows=True, **peak_kw)
 
 
 def _records_for_upload(records: np.ndarray, dt_values: np.ndarray) -> np.ndarray:
