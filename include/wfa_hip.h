@@ -160,6 +160,10 @@ int wfa_fused_baseline_filter_hits(wfa_ctx* ctx, int32_t bl_start, int32_t bl_en
  * -diff(row) in the row's dtype or float64 baseline - row), the height is measured on the row itself. */
 #define WFA_PEAK_SIGNAL_RECORDS 0
 #define WFA_PEAK_SIGNAL_ROWS 1
+/* WFA_PEAK_SIGNAL_ROWS_F64 = the streaming detector (streaming/cpu/signal_peaks.py:226-406): like _ROWS, but the row
+ * is converted to float64 first (detection on -diff in float64), rows are never cut at event_length, and the 'diff'
+ * height is cumsum(-diff(row))[end] - cumsum[start] with numpy's sequential cumsum, rounded to float32. */
+#define WFA_PEAK_SIGNAL_ROWS_F64 2
 int wfa_find_peaks_count(wfa_ctx* ctx, int source, int signal_mode, int use_derivative, double height, int has_threshold,
                          double threshold, int32_t distance, double prominence, double width, int height_method,
                          int32_t height_window_extension, int64_t* n_peaks);

@@ -646,6 +646,51 @@ def find_peak_hits_dense(data: np.ndarray, *, use_derivative=True, height=30.0, 
     return np.array(rows, dtype=HIT_DTYPE) if rows else np.zeros(0, dtype=HIT_DTYPE)
 
 
+def signal_peaks_rows(st_rows: np.ndarray, filtered_rows: np.ndarray, *, use_derivative=True, height=30.0,
+                      distance=2, prominence=0.7, width=4, threshold=None, height_method="diff",
+                      minmax_window_expand=2, explicit_dt=None, event_offset=0) -> np.ndarray:
+    """streaming/cpu/signal_peaks.py:226-406 (`compute_chunk` + `_find_peaks_in_waveform` +
+    `_calculate_peak_heights`): peaks of one chunk of rows; the filtered row is converted to float64 first."""
+    names = st_rows.dtype.names or ()
+    rows = []
+    for local_idx, (frow, srow) in enumerate(zip(filtered_rows, st_rows)):
+        w = np.asarray(frow["wave"] if getattr(frow, "dtype", None) is not None and frow.dtype.names else frow,
+                       dtype=np.float64)
+        baseline = srow["baseline"] if "baseline" in names else None
+        dt_ns = int(srow["dt"]) if "dt" in names else int(explicit_dt)
+        if use_derivative:
+            det = -np.diff(w)
+        elif baseline is not None:
+            det = baseline - w
+        else:
+            det = np.mean(w) - w
+        peaks, l_ips, r_ips = find_peaks_staged(det, height, threshold, distance, prominence, width)
+        if len(peaks) == 0:
+            continue
+        if height_method == "diff":
+            d = -np.diff(w)
+            cs = np.concatenate(([0.0], np.cumsum(d, dtype=np.float64)))
+            s_i = np.clip(np.rint(l_ips).astype(np.int64), 0, len(d))
+            e_i = np.clip(np.rint(r_ips).astype(np.int64), 0, len(d))
+            heights = np.where(e_i > s_i, cs[e_i] - cs[s_i], 0.0).astype(np.float32)
+        elif height_method == "minmax":
+            heights = np.zeros(len(peaks), dtype=np.float32)
+            for i, (l_ip, r_ip) in enumerate(zip(l_ips, r_ips)):
+                s_i, e_i = max(0, int(np.round(l_ip))), min(len(w) - 1, int(np.round(r_ip)))
+                w0, w1 = max(0, s_i - minmax_window_expand), min(len(w), e_i + minmax_window_expand)
+                heights[i] = np.max(w[w0:w1]) - np.min(w[w0:w1])
+        else:
+            raise ValueError(f"不支持的峰高计算方法: {height_method}")
+        if dt_ns <= 0:
+            raise ValueError("[signal_peaks_stream] dt must be > 0")
+        for pos, l_ip, r_ip, ph in zip(peaks, l_ips, r_ips, heights):
+            ts = int(int(srow["timestamp"]) + pos * (float(dt_ns) * 1e3))
+            rows.append((int(pos), float(ph), 0.0, float(l_ip), float(r_ip), dt_ns, ts,
+                         int(srow["board"]) if "board" in names else 0, int(srow["channel"]),
+                         int(srow["record_id"]) if "record_id" in names else event_offset + local_idx))
+    return np.array(rows, dtype=HIT_DTYPE) if rows else np.zeros(0, dtype=HIT_DTYPE)
+
+
 def _first_crossing(seg: np.ndarray, level, rising: bool, interpolate: bool):
     """waveform_width.py:332-374: first sample at/over (rising) or at/under (falling) `level`, refined by the
     straight line through its left neighbour.  Keeps numpy's scalar types exactly as the reference's

@@ -614,6 +614,45 @@ def stream_case(name):
     print(f"{name}: chunks in/out {[(len(out[t + '_in']), len(out[t + '_out'])) for t in 'abcd']} -> {os.path.getsize(path)} B")
 
 
+def sigpeaks_case(name, records, pool, configs):
+    """Reference SignalPeaksStreamPlugin (streaming/cpu/signal_peaks.py:36-406), serial path: the chunks it cuts per
+    channel / dt segment / time break / chunk_size, and the peak rows each chunk yields."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.plugins.builtin.cpu.filtering import FilteredWaveformsPlugin
+    from waveform_analysis.core.plugins.builtin.streaming.cpu.signal_peaks import SignalPeaksStreamPlugin
+
+    st = st_from_records(records, pool)
+    st["dt"][st["channel"] == 3] = 2                        # one channel samples faster
+    ch5 = np.flatnonzero(st["channel"] == 5)
+    st["dt"][ch5[len(ch5) // 2:]] = 8                       # a dt change inside a channel -> a new dt segment
+    ch7 = np.flatnonzero(st["channel"] == 7)
+    st["timestamp"][ch7[len(ch7) // 2:]] += 5 * 10**13      # a time break inside a channel
+    filt = FilteredWaveformsPlugin().compute(Ctx({"max_workers": 1}, {"st_waveforms": st}), "run")
+    out = {"st_waveforms": st, "filtered_waveforms": filt}
+    for k, cfg in enumerate(configs):
+        cfg = dict(cfg)
+        sc = cfg.pop("streaming_config")
+        p = SignalPeaksStreamPlugin()
+        chunks = list(p.compute(Ctx(cfg, {"st_waveforms": st, "filtered_waveforms": filt}), "run",
+                                streaming_config={"parallel": False, **sc}))
+        out[f"chunks_{k}"] = np.array([(c.start, c.end, len(c.data)) for c in chunks], dtype=np.int64).reshape(-1, 3)
+        out[f"rows_{k}"] = (np.concatenate([c.data for c in chunks]) if chunks
+                            else np.zeros(0, dtype=chunks[0].data.dtype if chunks else [("position", "i8")]))
+        p2 = SignalPeaksStreamPlugin()
+        p2._apply_streaming_config({"parallel": False, **sc})
+        p2._load_config(Ctx(cfg, {}))
+        ins = list(p2._get_input_chunks(Ctx(cfg, {"st_waveforms": st, "filtered_waveforms": filt}), "run"))
+        out[f"inputs_{k}"] = np.array([(c.start, c.end, len(c.data), c.metadata["event_offset"], c.metadata["channel_index"],
+                                         c.metadata["segment_id"], int(c.dt)) for c in ins], dtype=np.int64)
+    out["options_json"] = np.frombuffer(json.dumps(configs).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: " + ", ".join(f"cfg{k}: {len(out[f'inputs_{k}'])} in / {len(out[f'chunks_{k}'])} out / "
+                                   f"{len(out[f'rows_{k}'])} peaks" for k in range(len(configs))) +
+          f" -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -760,6 +799,17 @@ def main():
                              {"height_method": "diff", "height": 20.0, "width": 2},
                              {"use_derivative": False, "height": 25.0, "width": 2, "prominence": 3.0,
                               "height_method": "diff"}])
+
+    rec, pool = synth.make_run(160, "v1725", cfg=21)
+    sigpeaks_case("sigpeaks_v1725", rec, pool, [
+        {"height": 8.0, "width": 2, "streaming_config": {"chunk_size": 4}},
+        {"height": 8.0, "width": 2, "height_method": "minmax", "minmax_window_expand": 3,
+         "streaming_config": {"chunk_size": 3, "break_threshold_ps": 0}},
+        {"use_derivative": False, "height": 25.0, "width": 3, "prominence": 3.0, "distance": 1,
+         "streaming_config": {}},
+        {"use_derivative": False, "height": 25.0, "width": 3, "prominence": 3.0, "distance": 30,
+         "height_method": "minmax", "streaming_config": {"chunk_size": 7}},
+        {"height": 6.0, "width": 1, "prominence": 0.5, "threshold": 0.5, "streaming_config": {"chunk_size": 5}}])
 
     # event grouping of threshold hits from a 16-channel run and from a 256-channel run
     for preset, cfg, nrec in (("v1725", 8, 400), ("vx2730", 9, 600)):

@@ -13,7 +13,7 @@ from waveformanalysis_amd.channel_config import per_record_option, scatter_per_r
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_", "legacy_", "chunk_", "v1725bin_", "densehit_")):
+def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_", "legacy_", "chunk_", "v1725bin_", "densehit_", "sigpeaks_")):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
     return [n for n in names if not n.startswith(tuple(prefix_exclude))]
 
@@ -80,6 +80,17 @@ def densehit_record_lengths(case, tag, arr):
     """records/wave_pool event_length of each dense row, looked up by record_id (hit_finder.py:257-286)."""
     lookup = dict(zip(case[f"recid_{tag}"].tolist(), case[f"reclen_{tag}"].tolist()))
     return np.array([lookup[int(r)] for r in arr["record_id"]], dtype=np.int64)
+
+
+def sigpeaks_case_names():
+    return sorted(os.path.splitext(f)[0] for f in os.listdir(GOLDEN) if f.startswith("sigpeaks_") and f.endswith(".npz"))
+
+
+def load_sigpeaks(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["configs"] = json.loads(bytes(d.pop("options_json")).decode())
+    return d
 
 
 def merge_case_names():

@@ -89,11 +89,11 @@ def test_channel_config_layers():
 
 def test_plugin_contract_attributes():
     for p in hip_default():
-        assert p.provides and p.save_when == ("target" if p.provides == "filtered_waveforms" else "always")
-        assert p.output_dtype is not None or p.provides == "hit_grouped"  # DataFrame product
+        assert p.provides and p.save_when == {"filtered_waveforms": "target", "signal_peaks_stream": "never"}.get(p.provides, "always")
+        assert p.output_dtype is not None or p.provides in ("hit_grouped", "signal_peaks_stream")  # DataFrame / chunk stream
         assert "wave_source" in p.options or p.provides in (
             "wave_pool_filtered", "hit_grouped", "filtered_waveforms", "waveform_width", "s1_s2", "hit_merge_clusters",
-            "hit_merged", "hit_merged_components")
+            "hit_merged", "hit_merged_components", "signal_peaks_stream")
     bf = [p for p in hip_default() if p.provides == "basic_features"][0]
     assert bf.resolve_depends_on(SimpleContext({})) == ["st_waveforms"]  # reference default: wave_source="auto"
     assert bf.resolve_depends_on(SimpleContext({"use_filtered": True})) == ["filtered_waveforms"]

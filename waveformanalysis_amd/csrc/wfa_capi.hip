@@ -719,8 +719,8 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int signal_mode, int use_deriva
     if (distance < 1) return fail(WFA_E_INVALID, "`distance` must be greater or equal to 1");  // scipy's message
     if (height_method != WFA_HEIGHT_MINMAX && height_method != WFA_HEIGHT_DIFF)
         return fail(WFA_E_INVALID, "height_method must be WFA_HEIGHT_MINMAX or WFA_HEIGHT_DIFF");
-    if (signal_mode != WFA_PEAK_SIGNAL_RECORDS && signal_mode != WFA_PEAK_SIGNAL_ROWS)
-        return fail(WFA_E_INVALID, "signal_mode must be WFA_PEAK_SIGNAL_RECORDS or WFA_PEAK_SIGNAL_ROWS");
+    if (signal_mode < WFA_PEAK_SIGNAL_RECORDS || signal_mode > WFA_PEAK_SIGNAL_ROWS_F64)
+        return fail(WFA_E_INVALID, "signal_mode must be WFA_PEAK_SIGNAL_RECORDS, _ROWS or _ROWS_F64");
     c->n_peaks = -1;
     if (c->R == 0) { c->n_peaks = 0; *n_peaks = 0; return WFA_OK; }
     const int64_t R = c->R;
@@ -734,7 +734,7 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int signal_mode, int use_deriva
     pp.use_derivative = use_derivative ? 1 : 0; pp.hmin = height; pp.has_threshold = has_threshold ? 1 : 0;
     pp.tmin = threshold; pp.distance = distance; pp.pmin = prominence; pp.wmin = width;
     pp.ext = ext > 0 ? ext : 0; pp.height_diff = height_method == WFA_HEIGHT_DIFF;
-    pp.rows = signal_mode == WFA_PEAK_SIGNAL_ROWS;
+    pp.rows = signal_mode;
     const PoolView pv = pool_view(c);
     const RecView rv = rec_view(c);
     int* err = reinterpret_cast<int*>(c->cursor.ptr);

@@ -2452,7 +2452,7 @@ struct SignalAt {
     double b64;
     bool positive;
     int use_derivative;
-    int rows;  // WFA_PEAK_SIGNAL_ROWS: dense branch, the stored samples are the waveform (negative-going pulses)
+    int rows;  // WFA_PEAK_SIGNAL_ROWS / _ROWS_F64: the stored samples are the waveform (negative-going pulses)
     int L, n;  // samples in the record, samples of the detection signal
     // the waveform the height is measured on
     __device__ __forceinline__ double sig(int i) const {
@@ -2465,7 +2465,8 @@ struct SignalAt {
     __device__ __forceinline__ double det_of(float w0, float w1) const {
         if (rows) {
             if (!use_derivative) return b64 - (double)w0;                   // np.float64 baseline - row
-            if (SRC == WFA_SRC_RAW) return -((double)w1 - (double)w0);      // -np.diff(int16 row): exact
+            // -np.diff(int16 row) is exact; the streaming detector converts the row to float64 first
+            if (SRC == WFA_SRC_RAW || rows == WFA_PEAK_SIGNAL_ROWS_F64) return -((double)w1 - (double)w0);
             return (double)(-(w1 - w0));                                    // -np.diff(float32 row): float32
         }
         const float d0 = w0 - b32;
@@ -2544,7 +2545,15 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
     if (pp.height_diff) {
         ph = 0.0;
         if (end_idx > start_idx) {
-            if (S.rows && SRC == WFA_SRC_F32)  // np.sum(np.diff(-row)) of a float32 row stays float32
+            if (S.rows == WFA_PEAK_SIGNAL_ROWS_F64) {
+                // signal_peaks.py:365-375: cumsum(-diff(row))[end] - cumsum[start], np.cumsum is sequential
+                double acc = 0.0, at_start = 0.0;
+                for (int q = 0; q < end_idx; ++q) {
+                    if (q == start_idx) at_start = acc;
+                    acc += -(S.sig(q + 1) - S.sig(q));
+                }
+                ph = (double)(float)(acc - at_start);  // heights.astype(np.float32)
+            } else if (S.rows && SRC == WFA_SRC_F32)  // np.sum(np.diff(-row)) of a float32 row stays float32
                 ph = (double)np_pairwise_sum<float>([&](int q) { return (-S.xf[q + 1]) - (-S.xf[q]); }, start_idx,
                                                     end_idx - start_idx, pw_scratch, kPeakBlock);
             else
@@ -2562,7 +2571,7 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
             vmax = v > vmax ? v : vmax;
             vmin = v < vmin ? v : vmin;
         }
-        ph = S.rows && SRC == WFA_SRC_F32 ? (double)((float)vmax - (float)vmin) : vmax - vmin;
+        ph = S.rows == WFA_PEAK_SIGNAL_ROWS && SRC == WFA_SRC_F32 ? (double)((float)vmax - (float)vmin) : vmax - vmin;
     }
     const int dt_ns = rec.dt[r];
     put_i64(row, 0, (int64_t)peak);

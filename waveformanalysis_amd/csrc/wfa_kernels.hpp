@@ -102,7 +102,7 @@ struct PeakParams {
     double wmin;
     int ext;
     int height_diff;  // 1: height_method 'diff', 0: 'minmax'
-    int rows;         // 1: WFA_PEAK_SIGNAL_ROWS (dense branch)
+    int rows;         // WFA_PEAK_SIGNAL_* (0 records branch, 1 dense rows, 2 dense rows as float64)
 };
 
 struct FeatParams {

@@ -28,15 +28,11 @@ DENSE_RECORD_DTYPE = np.dtype(
 )
 
 
-def dense_pool(waveform_data: np.ndarray, what: str = "st_waveforms") -> tuple[np.ndarray, int, int]:
-    """(flat pool, source code, row length) of a dense structured array.
+def matrix_pool(wave: np.ndarray, what: str = "st_waveforms") -> tuple[np.ndarray, int, int]:
+    """(flat pool, source code, row length) of an (n_events, n_samples) int16 / uint16 / float32 matrix.
 
     int16 rows are viewed as uint16: ADC codes are non-negative (14/16-bit unsigned converters); a negative
     sample is refused rather than reinterpreted."""
-    names = waveform_data.dtype.names or ()
-    if "wave" not in names:
-        raise ValueError(f"{what} missing required 'wave' field")
-    wave = waveform_data["wave"]
     if wave.ndim != 2:
         raise ValueError(f"{what}['wave'] must be 2D (n_events, n_samples)")
     L = int(wave.shape[1])
@@ -50,6 +46,14 @@ def dense_pool(waveform_data: np.ndarray, what: str = "st_waveforms") -> tuple[n
             flat = flat.view(np.uint16)
         return flat, _lib.SRC_RAW, L
     raise ValueError(f"{what}['wave'] must be int16 or float32, got {wave.dtype}")
+
+
+def dense_pool(waveform_data: np.ndarray, what: str = "st_waveforms") -> tuple[np.ndarray, int, int]:
+    """matrix_pool of a dense structured array's `wave` field."""
+    names = waveform_data.dtype.names or ()
+    if "wave" not in names:
+        raise ValueError(f"{what} missing required 'wave' field")
+    return matrix_pool(waveform_data["wave"], what)
 
 
 def dense_records(waveform_data: np.ndarray, row_length: int, *, keep_record_id: bool = False,

@@ -207,14 +207,15 @@ class DeviceSession:
     def find_peaks(self, source: int = _lib.SRC_F32, use_derivative: bool = True, height: float = 30.0,
                    distance: int = 2, prominence: float = 0.7, width: float = 4, threshold: float | None = None,
                    height_method: str = "minmax", height_window_extension: int = 4,
-                   dense_rows: bool = False) -> np.ndarray:
-        """find_peaks-based hit detector (HitFinderPlugin) -> HIT_DTYPE rows.  dense_rows: the dense branch
-        (WFA_PEAK_SIGNAL_ROWS), the uploaded records describe the rows of an st_waveforms / filtered_waveforms array."""
+                   dense_rows: bool | int = False) -> np.ndarray:
+        """find_peaks-based hit detector (HitFinderPlugin) -> HIT_DTYPE rows.  dense_rows: True / 1 = the dense branch
+        (WFA_PEAK_SIGNAL_ROWS), the uploaded records describe the rows of an st_waveforms / filtered_waveforms array;
+        2 = the streaming detector's float64 rows (WFA_PEAK_SIGNAL_ROWS_F64)."""
         if height_method not in ("minmax", "diff"):
             raise ValueError(f"不支持的峰高计算方法: {height_method}")  # peak_finding.py:612
         n = C.c_int64(0)
         _lib.check(self._lib.wfa_find_peaks_count(
-            self._h, int(source), 1 if dense_rows else 0, int(bool(use_derivative)), float(height),
+            self._h, int(source), int(dense_rows), int(bool(use_derivative)), float(height),
             int(threshold is not None),
             float(threshold or 0.0), int(distance), float(prominence), float(width),
             1 if height_method == "diff" else 0, int(height_window_extension), C.byref(n)))

@@ -11,6 +11,7 @@ from .hit_finder import HipHitFinderPlugin
 from .hit_grouped import HipHitGroupedPlugin
 from .hit_merge import HipHitMergeClustersPlugin, HipHitMergedComponentsPlugin, HipHitMergePlugin
 from .s1_s2 import HipS1S2ClassifierPlugin
+from .signal_peaks import HipSignalPeaksStreamPlugin
 from .threshold_hit import HipThresholdHitPlugin
 from .wave_pool_filtered import HipWavePoolFilteredPlugin
 from .waveform_width import HipWaveformWidthPlugin
@@ -21,10 +22,11 @@ def hip_default():
     return [HipWavePoolFilteredPlugin(), HipThresholdHitPlugin(), HipBasicFeaturesPlugin(),
             HipWaveformWidthIntegralPlugin(), HipHitGroupedPlugin(), HipHitFinderPlugin(),
             HipFilteredWaveformsPlugin(), HipWaveformWidthPlugin(), HipS1S2ClassifierPlugin(),
-            HipHitMergeClustersPlugin(), HipHitMergePlugin(), HipHitMergedComponentsPlugin()]
+            HipHitMergeClustersPlugin(), HipHitMergePlugin(), HipHitMergedComponentsPlugin(),
+            HipSignalPeaksStreamPlugin()]
 
 
 __all__ = ["HipWavePoolFilteredPlugin", "HipThresholdHitPlugin", "HipBasicFeaturesPlugin",
            "HipWaveformWidthIntegralPlugin", "HipHitGroupedPlugin", "HipHitFinderPlugin", "HipFilteredWaveformsPlugin",
            "HipWaveformWidthPlugin", "HipS1S2ClassifierPlugin", "HipHitMergeClustersPlugin",
-           "HipHitMergePlugin", "HipHitMergedComponentsPlugin", "hip_default"]
+           "HipHitMergePlugin", "HipHitMergedComponentsPlugin", "HipSignalPeaksStreamPlugin", "hip_default"]
