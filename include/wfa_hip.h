@@ -241,10 +241,29 @@ int wfa_records_sort(wfa_ctx* ctx, int64_t n_records, const int64_t* timestamp, 
 /* K13 pack the wave slices of the records, given in OUTPUT order, into one contiguous pool
  * (records_builder.py:195-207, 400-409).  src_pool: the concatenated source samples (uint16 bit patterns);
  * out_offset[r] receives the running sum of max(length, 0).  The packed pool becomes the resident wave_pool of the
- * context (records must be uploaded again); out_pool, when not NULL, also receives it. */
+ * context (records must be uploaded again); out_pool, when not NULL, also receives it.  src_pool = NULL with
+ * src_samples > 0 takes the samples the last wfa_csv_decode_fill left on the device. */
 int wfa_pool_gather(wfa_ctx* ctx, int64_t n_records, const int64_t* src_offset, const int32_t* length,
                     const uint16_t* src_pool, int64_t src_samples, int64_t* out_offset, uint16_t* out_pool,
                     int64_t out_samples);
+
+/* K15 CAEN VX2730 CSV text -> integers on the device (reference: utils/formats/vx2730.py:78-110 column layout,
+ * :193-340 `VX2730Reader.read_file` -- its polars / pyarrow / pandas backends all yield these integers; consumer
+ * processing/records_builder.py:212-302).  text = the bytes of one or more files after their header rows: rows end
+ * with '\n' (a '\r' before it is dropped, a last row without '\n' counts), fields are separated by `delimiter`.
+ * _count uploads the text, indexes the rows and counts their fields; n_rows includes empty rows (0 fields).
+ * n_samples = sum over rows of max(n_fields - samples_start, 0).
+ * _fill parses columns meta_cols[0..n_meta) (each < samples_start) as int64 into meta[n_rows x n_meta] and the fields
+ * from samples_start on as uint16 ADC codes into the ragged pool samples[sample_offset[r] ...]; row_offset[r] = byte
+ * offset of row r in text (maps rows back to files), n_fields[r] = its field count.  Any output pointer but meta may
+ * be NULL.  The samples stay resident: wfa_pool_gather with src_pool = NULL, src_samples = n_samples packs them
+ * without a host round trip.  A requested field that is not a decimal integer, or a sample outside 0..65535, fails
+ * with WFA_E_INVALID naming the row and field; other columns (ENERGY, FLAGS as hex, ...) are never parsed. */
+int wfa_csv_decode_count(wfa_ctx* ctx, const uint8_t* text, int64_t n_bytes, int delimiter, int32_t samples_start,
+                         int64_t* n_rows, int64_t* n_samples);
+int wfa_csv_decode_fill(wfa_ctx* ctx, int64_t n_rows, int32_t n_meta, const int32_t* meta_cols, int64_t* meta,
+                        int64_t* row_offset, int32_t* n_fields, int64_t* sample_offset, uint16_t* samples,
+                        int64_t n_samples);
 
 /* Wave index of a CAEN V1725 DAW_DEMO binary stream held in host memory (reference: utils/formats/v1725.py:66-114
  * `V1725Reader.iter_waves`): 16-byte event header (channel mask in bytes 4 and 11), per set channel a 12-byte

@@ -1038,3 +1038,72 @@ def build_records_from_v1725_blobs(blobs, boards, dt_ns: int):
     if not parts:
         return np.zeros(0, dtype=RECORDS_DTYPE), np.zeros(0, dtype=np.uint16)
     return parts[0] if len(parts) == 1 else merge_records_parts(parts)
+
+
+def vx2730_rows(text: bytes, is_first_file: bool) -> np.ndarray:
+    """utils/formats/vx2730.py:165-340: header rows by content (first / second line starting BOARD;CHANNEL;TIMETAG),
+    else 2 for the first file of a channel and 0 for the others; blank lines dropped; every other row a list of
+    integers.  Columns that are not decimal (the hex FLAGS) become 0 here -- the builder never reads them."""
+    lines = text.decode("utf-8", errors="ignore").split("\n")
+
+    def is_header(line):
+        f = [x.strip().upper() for x in line.strip().split(";")]
+        return len(f) >= 3 and tuple(f[:3]) == ("BOARD", "CHANNEL", "TIMETAG")
+
+    skip = 1 if lines and is_header(lines[0]) else 2 if len(lines) > 1 and lines[1] and is_header(lines[1]) else \
+        (2 if is_first_file else 0)
+    rows = []
+    for line in lines[skip:]:
+        line = line.rstrip("\r")
+        if not line:
+            continue
+        vals = []
+        for k, f in enumerate(line.split(";")):
+            try:
+                vals.append(int(f))
+            except ValueError:
+                if k in (0, 1, 2) or k >= 7:
+                    raise
+                vals.append(0)
+        rows.append(vals)
+    if not rows:
+        return np.zeros((0, 0), dtype=np.int64)
+    if len({len(r) for r in rows}) != 1:
+        raise ValueError("rows with differing field counts")
+    return np.array(rows, dtype=np.int64)
+
+
+def build_records_from_vx2730_texts(texts, default_dt_ns: int = 1, baseline_samples=None, epoch_ns=None):
+    """records_builder.py:212-302 + 341-426 for the vx2730 adapter: texts = per-channel lists of file contents.  One
+    sorted part per file, parts merged with the (part, row) tie-break == the stable sort of all rows."""
+    parts = []
+    for files in texts:
+        for k, text in enumerate(files):
+            raw = vx2730_rows(text, is_first_file=(k == 0))
+            if raw.size == 0:
+                continue
+            n = len(raw)
+            rec = np.zeros(n, dtype=RECORDS_DTYPE)
+            rec["timestamp"] = raw[:, 2]
+            rec["board"], rec["channel"] = raw[:, 0].astype(np.int16), raw[:, 1].astype(np.int16)
+            if baseline_samples is None:
+                b0, b1 = 7, 47
+            elif isinstance(baseline_samples, (tuple, list)):
+                b0, b1 = 7 + baseline_samples[0], 7 + baseline_samples[1]
+            else:
+                b0, b1 = 7, 7 + int(baseline_samples)
+            b1 = min(b1, raw.shape[1])
+            rec["baseline"] = np.mean(raw[:, b0:b1].astype(float), axis=1) if b1 > b0 else np.nan
+            rec["baseline_upstream"] = np.nan
+            rec["polarity"] = "unknown"
+            rec["dt"] = default_dt_ns
+            rec["time"] = rec["timestamp"] // 1000 if epoch_ns is None else np.int64(epoch_ns) + rec["timestamp"] // 1000
+            wave = raw[:, 7:]
+            rec["event_length"] = wave.shape[1]
+            order = records_sort_order(rec)
+            rec = rec[order]
+            rec["wave_offset"] = np.arange(n, dtype=np.int64) * wave.shape[1]
+            rec["record_id"] = np.arange(n)
+            parts.append((rec, np.asarray(wave[order], dtype=np.uint16).reshape(-1)))
+    return merge_records_parts(parts)
+

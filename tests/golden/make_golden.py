@@ -653,6 +653,64 @@ def sigpeaks_case(name, records, pool, configs):
           f" -> {os.path.getsize(path)} B")
 
 
+def vx2730csv_case(name, seed):
+    """Reference build_records_from_raw_files(adapter_name="vx2730") (records_builder.py:524-642, 834-867; reader
+    utils/formats/vx2730.py:141-480) on CSV files written here: 3 channel lists, header variants (one header row,
+    the legacy two rows, none), a hex FLAGS column, CRLF line ends, a trailing blank line, timestamp ties across
+    channels, a channel with another record length.  The fixture stores the file texts and the bundles."""
+    if not name.startswith(ONLY):
+        return
+    from waveform_analysis.core.processing.records_builder import build_records_from_raw_files
+
+    rng = np.random.default_rng(seed)
+    tmp = tempfile.mkdtemp(prefix="wfa_csv_")
+    hdr = "BOARD;CHANNEL;TIMETAG;ENERGY;ENERGYSHORT;FLAGS;PROBE_CODE;SAMPLES"
+
+    def rows(board, channel, n, L, t0):
+        ts = t0 + np.sort(rng.integers(0, 40, n)) * 1_000_000      # few distinct values: ties across channels
+        out = []
+        for t in ts:
+            w = 8000 + np.round(rng.normal(0, 3, L)).astype(int)
+            a = int(rng.integers(60, max(61, L - 20)))
+            w[a : a + 12] -= int(rng.integers(20, 3000))
+            w = np.clip(w, 0, 16383)
+            out.append(f"{board};{channel};{int(t)};{int(rng.integers(0, 5000))};{int(rng.integers(0, 900))};"
+                       f"0x{int(rng.integers(0, 2**15)):x};1;" + ";".join(str(int(v)) for v in w))
+        return out
+
+    files, texts = [], {}
+
+    def put(fname, text):
+        path = os.path.join(tmp, fname)
+        with open(path, "w", encoding="utf-8", newline="") as fh:
+            fh.write(text)
+        texts[fname] = text
+        return path
+
+    ch0 = [put("DataR_CH0@VX2730_run.CSV", hdr + "\n" + "\n".join(rows(0, 0, 9, 96, 5_000_000)) + "\n"),
+           put("DataR_CH0@VX2730_run_1.CSV", "\n".join(rows(0, 0, 7, 96, 9_000_000)) + "\n"),
+           put("DataR_CH0@VX2730_run_2.CSV", "\r\n".join(rows(0, 0, 5, 96, 2_000_000)) + "\r\n")]
+    ch1 = [put("DataR_CH1@VX2730_run.CSV", "some preamble line\n" + hdr + "\n" + "\n".join(rows(0, 1, 8, 96, 5_000_000)) + "\n\n"),
+           put("DataR_CH1@VX2730_run_1.CSV", "\n".join(rows(0, 1, 6, 96, 7_000_000)))]          # no final newline
+    ch2 = [put("DataR_CH5@VX2730_run.CSV", hdr + "\n" + "\n".join(rows(1, 5, 10, 130, 4_000_000)) + "\n")]
+    files = [ch0, [], ch1, ch2]
+    out = {}
+    names = [[os.path.basename(p) for p in group] for group in files]
+    variants = [{"default_dt_ns": 2}, {"default_dt_ns": 2, "baseline_samples": 25},
+                {"default_dt_ns": 4, "baseline_samples": (10, 60), "epoch_ns": 1_700_000_000_000_000_000},
+                {"default_dt_ns": 2, "part_size": 4}]
+    for k, kw in enumerate(variants):
+        b = build_records_from_raw_files(files, adapter_name="vx2730", show_progress=False,
+                                         **({"part_size": None} | kw))
+        out[f"records_{k}"], out[f"wave_pool_{k}"] = b.records, b.wave_pool
+    for fname, text in texts.items():
+        out["text_" + fname.replace("@", "_at_").replace(".", "_dot_")] = np.frombuffer(text.encode(), dtype=np.uint8)
+    out["options_json"] = np.frombuffer(json.dumps({"files": names, "variants": variants}).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(out['records_0'])} records, {len(out['wave_pool_0'])} samples -> {os.path.getsize(path)} B")
+
+
 def grouping_case(name, hits, windows):
     """Reference group_hit_windows (core/processing/event_grouping.py:286-471) on hit rows, flattened."""
     if not name.startswith(ONLY):
@@ -810,6 +868,8 @@ def main():
         {"use_derivative": False, "height": 25.0, "width": 3, "prominence": 3.0, "distance": 30,
          "height_method": "minmax", "streaming_config": {"chunk_size": 7}},
         {"height": 6.0, "width": 1, "prominence": 0.5, "threshold": 0.5, "streaming_config": {"chunk_size": 5}}])
+
+    vx2730csv_case("vx2730csv_files", 77)
 
     # event grouping of threshold hits from a 16-channel run and from a 256-channel run
     for preset, cfg, nrec in (("v1725", 8, 400), ("vx2730", 9, 600)):

@@ -13,7 +13,7 @@ from waveformanalysis_amd.channel_config import per_record_option, scatter_per_r
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_", "legacy_", "chunk_", "v1725bin_", "densehit_", "sigpeaks_")):
+def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_", "legacy_", "chunk_", "v1725bin_", "densehit_", "sigpeaks_", "vx2730csv_")):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
     return [n for n in names if not n.startswith(tuple(prefix_exclude))]
 
@@ -91,6 +91,19 @@ def load_sigpeaks(name):
     d = {k: z[k] for k in z.files}
     d["configs"] = json.loads(bytes(d.pop("options_json")).decode())
     return d
+
+
+def load_vx2730csv(name="vx2730csv_files"):
+    """-> (per-channel lists of (file name, text bytes), variants, fixture dict)."""
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    opt = json.loads(bytes(d.pop("options_json")).decode())
+    key = lambda f: "text_" + f.replace("@", "_at_").replace(".", "_dot_")  # noqa: E731
+    groups = [[(f, bytes(d[key(f)])) for f in group] for group in opt["files"]]
+    for v in opt["variants"]:
+        if isinstance(v.get("baseline_samples"), list):
+            v["baseline_samples"] = tuple(v["baseline_samples"])
+    return groups, opt["variants"], d
 
 
 def merge_case_names():

@@ -115,6 +115,11 @@ struct wfa_ctx {
     int64_t ht_n = -1, ht_groups = 0;
     int ht_kind = 0;  // 1 = event grouping, 2 = hit merge
     int64_t* ht_perm = nullptr;
+    // CSV decode (wfa_hits.hip): rows / samples of the last wfa_csv_decode_count pass; the samples stay resident
+    int64_t csv_rows = -1, csv_samples = -1, csv_bytes = 0;
+    int32_t csv_samples_start = 0;
+    int csv_delim = ';';
+    bool csv_filled = false;
     wfa::DevBuf bw_scratch;  // float64 forward pass of sosfiltfilt, [sample][record-in-batch]
 
     // profiling: HIP events around every launch on the context's stream.  The pairs are only recorded while the

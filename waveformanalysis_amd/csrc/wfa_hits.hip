@@ -25,7 +25,7 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kTB - 1) / kTB); 
 enum Slot {
     S_TS, S_POS, S_START, S_END, S_DT, S_BOARD, S_CHAN, S_RID, S_HEIGHT, S_INTEGRAL,
     S_ABS0, S_ABS1, S_K0, S_K1, S_K2, S_K3, S_K4, S_KTMP0, S_KTMP1, S_PERM0, S_PERM1, S_CUB,
-    S_F0, S_F1, S_FLAG, S_ID, S_OUT0, S_OUT1, S_OUT2, S_OUT3, S_OUT4, S_OUT5, S_OUT6, S_OUT7, S_CNT, S_SG, S_N
+    S_F0, S_F1, S_FLAG, S_ID, S_OUT0, S_OUT1, S_OUT2, S_OUT3, S_OUT4, S_OUT5, S_OUT6, S_OUT7, S_CNT, S_SG, S_CSV, S_N
 };
 static_assert(S_N <= 40, "wfa_ctx::ht is too small");
 
@@ -343,6 +343,150 @@ __global__ __launch_bounds__(128) void k_pool_gather(int64_t n, const int64_t* _
     }
 }
 
+
+// ---- K15: delimiter-separated integer text -> int64 columns + uint16 samples (CAEN VX2730 CSV) ------------------
+// (utils/formats/vx2730.py:193-340: every reader backend yields the same integers; records_builder.py:212-302 then
+// uses columns board / channel / timestamp and the samples from `samples_start` to the end of the row.)
+// A row is the bytes between two '\n' (a trailing '\r' dropped); an empty row has 0 fields.  One wave decodes one
+// row in 1-KiB tiles: the tile (+ 32 bytes of lookahead) is staged in LDS with 16-byte loads, every lane counts the
+// delimiters of its 16 bytes, a wave prefix sum turns that into the field index, and the lane parses the fields that
+// FOLLOW its delimiters (a decimal integer is at most 20 characters, so the lookahead always covers it).
+constexpr int kCsvTile = 1024;
+constexpr int kCsvLook = 32;
+constexpr int kCsvMaxMeta = 8;
+constexpr int kCsvErrSyntax = 1, kCsvErrRange = 2;
+
+struct IsNewline {
+    const uint8_t* t;
+    __device__ bool operator()(const int64_t& i) const { return t[i] == '\n'; }
+};
+
+__global__ void k_csv_lines(int64_t n_lines, int64_t n_nl, int64_t n_bytes, const uint8_t* __restrict__ text,
+                            const int64_t* __restrict__ nl, int64_t* __restrict__ row_start, int64_t* __restrict__ row_end) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n_lines) return;
+    const int64_t s = i == 0 ? 0 : nl[i - 1] + 1;
+    int64_t e = i < n_nl ? nl[i] : n_bytes;
+    if (e > s && text[e - 1] == '\r') --e;
+    row_start[i] = s;
+    row_end[i] = e;
+}
+
+__device__ __forceinline__ uint32_t csv_delim_mask(const uint4& w, uint8_t delim) {
+    const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m |= (uint32_t)(((v[k >> 2] >> ((k & 3) * 8)) & 0xffu) == delim) << k;
+    return m;
+}
+
+// restrict a 16-bit byte mask of the chunk at absolute offset `abs0` to the bytes in [lo, hi)
+__device__ __forceinline__ uint32_t csv_clip(uint32_t m, int64_t abs0, int64_t lo, int64_t hi) {
+    if (abs0 + 16 <= lo || abs0 >= hi) return 0;
+    if (abs0 < lo) m &= ~0u << (int)(lo - abs0);
+    if (abs0 + 16 > hi) m &= (1u << (int)(hi - abs0)) - 1u;
+    return m;
+}
+
+// fields per row and samples per row (fields from samples_start on); one wave per row
+__global__ __launch_bounds__(64) void k_csv_count(int64_t n_rows, const uint8_t* __restrict__ text,
+                                                  const int64_t* __restrict__ row_start, const int64_t* __restrict__ row_end,
+                                                  uint8_t delim, int32_t samples_start, int32_t* __restrict__ n_fields,
+                                                  int64_t* __restrict__ n_samples) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x;
+    const int64_t lo = row_start[r], hi = row_end[r];
+    int cnt = 0;
+    for (int64_t a = (lo & ~15ll) + lane * 16; a < hi; a += 64 * 16) {
+        const uint4 w = *reinterpret_cast<const uint4*>(text + a);
+        cnt += __popc(csv_clip(csv_delim_mask(w, delim), a, lo, hi));
+    }
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (lane == 0) {
+        const int nf = hi > lo ? cnt + 1 : 0;
+        n_fields[r] = nf;
+        n_samples[r] = nf > samples_start ? nf - samples_start : 0;
+    }
+}
+
+struct CsvCols {
+    int32_t n_meta;
+    int32_t col[kCsvMaxMeta];
+};
+
+__global__ __launch_bounds__(64) void k_csv_decode(int64_t n_rows, const uint8_t* __restrict__ text,
+                                                   const int64_t* __restrict__ row_start, const int64_t* __restrict__ row_end,
+                                                   uint8_t delim, int32_t samples_start, CsvCols cols,
+                                                   const int64_t* __restrict__ sample_offset, int64_t* __restrict__ meta,
+                                                   uint16_t* __restrict__ samples, unsigned long long* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kCsvTile + kCsvLook];
+    const int64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x;
+    const int64_t lo = row_start[r], hi = row_end[r];
+    if (hi <= lo) return;
+    const int64_t s_off = sample_offset[r];
+    int field_base = 0;  // delimiters of the row before this tile
+    for (int64_t t0 = lo & ~15ll; t0 < hi; t0 += kCsvTile) {
+        __syncthreads();
+        const uint4 w = *reinterpret_cast<const uint4*>(text + t0 + lane * 16);
+        *reinterpret_cast<uint4*>(tile + lane * 16) = w;
+        if (lane < kCsvLook / 16)
+            *reinterpret_cast<uint4*>(tile + kCsvTile + lane * 16) =
+                *reinterpret_cast<const uint4*>(text + t0 + kCsvTile + lane * 16);
+        __syncthreads();
+        const int64_t a = t0 + lane * 16;
+        uint32_t m = csv_clip(csv_delim_mask(w, delim), a, lo, hi);
+        const int mine = __popc(m);
+        int incl = mine;  // inclusive prefix over the wave
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        int f = field_base + incl - mine;  // index of the field that CONTAINS this lane's first byte
+        // the lane owning the row's first byte also parses field 0 (a virtual delimiter before the row)
+        bool first = lo >= a && lo < a + 16;
+        while (first || m) {
+            int64_t q;  // absolute offset of the field's first character
+            if (first) { q = lo; first = false; }
+            else { const int b = __ffs(m) - 1; m &= m - 1; q = a + b + 1; ++f; }
+            const int fidx = (q == lo) ? 0 : f;
+            int mj = -1;
+            for (int j = 0; j < cols.n_meta; ++j) if (cols.col[j] == fidx) mj = j;
+            const bool is_sample = fidx >= samples_start;
+            if (mj < 0 && !is_sample) continue;
+            int p = (int)(q - t0);
+            const int p_end = (int)((hi - t0) < (int64_t)(kCsvTile + kCsvLook) ? (hi - t0) : (kCsvTile + kCsvLook));
+            bool neg = false, any = false, bad = false;
+            unsigned long long v = 0;
+            if (p < p_end && (tile[p] == '-' || tile[p] == '+')) { neg = tile[p] == '-'; ++p; }
+            int digits = 0;
+            for (; p < p_end; ++p) {
+                const uint8_t ch = tile[p];
+                if (ch == delim) break;
+                if (ch < '0' || ch > '9' || ++digits > 19) { bad = true; break; }
+                v = v * 10ull + (unsigned long long)(ch - '0');
+                any = true;
+            }
+            if (!any || bad || v > 0x7fffffffffffffffull) {
+                atomicMin(err, ((unsigned long long)r << 24) | ((unsigned long long)(fidx & 0x3fffff) << 2) | kCsvErrSyntax);
+                continue;
+            }
+            const int64_t val = neg ? -(int64_t)v : (int64_t)v;
+            if (mj >= 0) meta[r * cols.n_meta + mj] = val;
+            if (is_sample) {
+                if (val < 0 || val > 65535)
+                    atomicMin(err, ((unsigned long long)r << 24) | ((unsigned long long)(fidx & 0x3fffff) << 2) | kCsvErrRange);
+                else
+                    samples[s_off + (fidx - samples_start)] = (uint16_t)val;
+            }
+        }
+        int total = __shfl(incl, 63);
+        field_base += total;
+    }
+}
+
 }  // namespace
 }  // namespace wfa
 
@@ -601,7 +745,9 @@ int wfa_pool_gather(wfa_ctx* c, int64_t n, const int64_t* src_offset, const int3
     if (rc) return rc;
     if (n < 0 || src_samples < 0 || out_samples < 0) return fail(WFA_E_INVALID, "negative size");
     if (n > 0 && (!src_offset || !length || !out_offset)) return fail(WFA_E_INVALID, "null argument");
-    if (src_samples > 0 && !src_pool) return fail(WFA_E_INVALID, "src_pool is null");
+    const bool from_csv = !src_pool && src_samples > 0;  // the samples the last wfa_csv_decode_fill left on the device
+    if (from_csv && (!c->csv_filled || c->csv_samples != src_samples))
+        return fail(WFA_E_INVALID, "src_pool is null and no decoded CSV samples of that size are resident");
     // every slice is checked before a kernel indexes with it; offsets of the packed pool are the running sum
     int64_t cursor = 0;
     for (int64_t r = 0; r < n; ++r) {
@@ -617,7 +763,9 @@ int wfa_pool_gather(wfa_ctx* c, int64_t n, const int64_t* src_offset, const int3
     uint16_t* d_src;
     int64_t *d_so, *d_do;
     int32_t* d_len;
-    if ((rc = upload(c, S_F0, src_pool, src_samples, &d_src)) || (rc = upload(c, S_K0, src_offset, n, &d_so)) ||
+    if (from_csv) d_src = c->ht[S_CSV].as<uint16_t>();
+    else if ((rc = upload(c, S_F0, src_pool, src_samples, &d_src))) return rc;
+    if ((rc = upload(c, S_K0, src_offset, n, &d_so)) ||
         (rc = upload(c, S_K1, (const int64_t*)out_offset, n, &d_do)) || (rc = upload(c, S_K2, length, n, &d_len)))
         return rc;
     if ((rc = c->pool_u16.ensure((size_t)(out_samples > 0 ? out_samples : 1) * sizeof(uint16_t)))) return rc;
@@ -679,6 +827,120 @@ int wfa_v1725_index(const uint8_t* buf, int64_t n_bytes, int64_t capacity, int16
         }
     }
     *n_waves = k;
+    return WFA_OK;
+}
+
+// K15 entry points: see include/wfa_hip.h
+int wfa_csv_decode_count(wfa_ctx* c, const uint8_t* text, int64_t n_bytes, int delimiter, int32_t samples_start,
+                         int64_t* n_rows, int64_t* n_samples) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n_bytes < 0 || !n_rows || !n_samples) return fail(WFA_E_INVALID, "bad arguments");
+    if (n_bytes > 0 && !text) return fail(WFA_E_INVALID, "text is null");
+    if (delimiter <= 0 || delimiter > 127 || delimiter == '\n' || delimiter == '\r' || (delimiter >= '0' && delimiter <= '9') ||
+        delimiter == '-' || delimiter == '+')
+        return fail(WFA_E_INVALID, "delimiter must be an ASCII character that is not a digit, a sign or a line end");
+    if (samples_start < 0) return fail(WFA_E_INVALID, "samples_start must be >= 0");
+    if (n_bytes > 0x7fffffff) return fail(WFA_E_LIMIT, "text of %lld bytes; one decode call handles < 2^31 bytes", (long long)n_bytes);
+    c->csv_rows = -1; c->csv_samples = -1; c->csv_filled = false;
+    *n_rows = 0; *n_samples = 0;
+    if (n_bytes == 0) { c->csv_rows = 0; c->csv_samples = 0; c->csv_bytes = 0; return WFA_OK; }
+    uint8_t* d_text;
+    if ((rc = slot<uint8_t>(c, S_ABS0, n_bytes + 2 * kCsvTile, &d_text))) return rc;
+    WFA_HIP_CHECK(hipMemcpyAsync(d_text, text, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+    WFA_HIP_CHECK(hipMemsetAsync(d_text + n_bytes, 0, 2 * kCsvTile, c->stream));  // tiles read past the last row
+    int64_t *d_nl, *d_cnt;
+    if ((rc = slot<int64_t>(c, S_K0, n_bytes, &d_nl)) || (rc = slot<int64_t>(c, S_CNT, 2, &d_cnt))) return rc;
+    LaunchTimer t(c);
+    hipcub::CountingInputIterator<int64_t> idx(0);
+    size_t tmp = 0;
+    WFA_HIP_CHECK(hipcub::DeviceSelect::If(nullptr, tmp, idx, d_nl, d_cnt, (int)n_bytes, IsNewline{d_text}, c->stream));
+    if ((rc = c->ht[S_CUB].ensure(tmp))) return rc;
+    WFA_HIP_CHECK(hipcub::DeviceSelect::If(c->ht[S_CUB].ptr, tmp, idx, d_nl, d_cnt, (int)n_bytes, IsNewline{d_text}, c->stream));
+    int64_t n_nl = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&n_nl, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const int64_t n_lines = n_nl + (text[n_bytes - 1] != '\n' ? 1 : 0);
+    int64_t *d_rs, *d_re, *d_ns, *d_so;
+    int32_t* d_nf;
+    if ((rc = slot<int64_t>(c, S_K1, n_lines, &d_rs)) || (rc = slot<int64_t>(c, S_K2, n_lines, &d_re)) ||
+        (rc = slot<int32_t>(c, S_OUT0, n_lines, &d_nf)) || (rc = slot<int64_t>(c, S_K3, n_lines, &d_ns)) ||
+        (rc = slot<int64_t>(c, S_K4, n_lines + 1, &d_so)))
+        return rc;
+    if (n_lines > 0) {
+        hipLaunchKernelGGL(k_csv_lines, dim3(blocks_for(n_lines)), dim3(kTB), 0, c->stream, n_lines, n_nl, n_bytes, d_text,
+                           d_nl, d_rs, d_re);
+        hipLaunchKernelGGL(k_csv_count, dim3((unsigned)n_lines), dim3(64), 0, c->stream, n_lines, d_text, d_rs, d_re,
+                           (uint8_t)delimiter, samples_start, d_nf, d_ns);
+        size_t tb = 0;
+        WFA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_ns, d_so, (int)n_lines, c->stream));
+        if ((rc = c->ht[S_CUB].ensure(tb))) return rc;
+        WFA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->ht[S_CUB].ptr, tb, d_ns, d_so, (int)n_lines, c->stream));
+    }
+    WFA_HIP_CHECK(hipGetLastError());
+    if ((rc = t.end("csv: index rows + count fields"))) return rc;
+    int64_t last_off = 0, last_n = 0;
+    if (n_lines > 0) {
+        WFA_HIP_CHECK(hipMemcpyAsync(&last_off, d_so + n_lines - 1, 8, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipMemcpyAsync(&last_n, d_ns + n_lines - 1, 8, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    c->csv_rows = n_lines; c->csv_samples = last_off + last_n; c->csv_bytes = n_bytes;
+    c->csv_samples_start = samples_start; c->csv_delim = delimiter;
+    *n_rows = n_lines; *n_samples = c->csv_samples;
+    return WFA_OK;
+}
+
+int wfa_csv_decode_fill(wfa_ctx* c, int64_t n_rows, int32_t n_meta, const int32_t* meta_cols, int64_t* meta,
+                        int64_t* row_offset, int32_t* n_fields, int64_t* sample_offset, uint16_t* samples,
+                        int64_t n_samples) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (c->csv_rows < 0) return fail(WFA_E_STATE, "no wfa_csv_decode_count pass has been run");
+    if (n_rows != c->csv_rows || n_samples != c->csv_samples)
+        return fail(WFA_E_INVALID, "the count pass found %lld rows / %lld samples", (long long)c->csv_rows, (long long)c->csv_samples);
+    if (n_meta < 0 || n_meta > kCsvMaxMeta) return fail(WFA_E_INVALID, "n_meta must be 0..%d", kCsvMaxMeta);
+    if (n_meta > 0 && (!meta_cols || !meta)) return fail(WFA_E_INVALID, "null meta arguments");
+    CsvCols cols{};
+    cols.n_meta = n_meta;
+    for (int j = 0; j < n_meta; ++j) {
+        if (meta_cols[j] < 0 || meta_cols[j] >= c->csv_samples_start)
+            return fail(WFA_E_INVALID, "meta column %d is not before samples_start = %d", meta_cols[j], c->csv_samples_start);
+        cols.col[j] = meta_cols[j];
+    }
+    if (n_rows == 0) { c->csv_filled = true; return WFA_OK; }
+    int64_t* d_meta;
+    uint16_t* d_samples;
+    unsigned long long* d_err;
+    if ((rc = slot<int64_t>(c, S_OUT1, n_rows * (n_meta > 0 ? n_meta : 1), &d_meta)) ||
+        (rc = slot<uint16_t>(c, S_CSV, n_samples, &d_samples)) || (rc = slot<unsigned long long>(c, S_FLAG, 1, &d_err)))
+        return rc;
+    WFA_HIP_CHECK(hipMemsetAsync(d_err, 0xff, 8, c->stream));
+    WFA_HIP_CHECK(hipMemsetAsync(d_meta, 0, (size_t)n_rows * (n_meta > 0 ? n_meta : 1) * 8, c->stream));
+    {
+        LaunchTimer t(c);
+        hipLaunchKernelGGL(k_csv_decode, dim3((unsigned)n_rows), dim3(64), 0, c->stream, n_rows, c->ht[S_ABS0].as<uint8_t>(),
+                           c->ht[S_K1].as<int64_t>(), c->ht[S_K2].as<int64_t>(), (uint8_t)c->csv_delim, c->csv_samples_start,
+                           cols, c->ht[S_K4].as<int64_t>(), d_meta, d_samples, d_err);
+        WFA_HIP_CHECK(hipGetLastError());
+        if ((rc = t.end("k_csv_decode"))) return rc;
+    }
+    unsigned long long err = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_meta > 0) WFA_HIP_CHECK(hipMemcpyAsync(meta, d_meta, (size_t)n_rows * n_meta * 8, hipMemcpyDeviceToHost, c->stream));
+    if (row_offset) WFA_HIP_CHECK(hipMemcpyAsync(row_offset, c->ht[S_K1].ptr, (size_t)n_rows * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_fields) WFA_HIP_CHECK(hipMemcpyAsync(n_fields, c->ht[S_OUT0].ptr, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    if (sample_offset) WFA_HIP_CHECK(hipMemcpyAsync(sample_offset, c->ht[S_K4].ptr, (size_t)n_rows * 8, hipMemcpyDeviceToHost, c->stream));
+    if (samples && n_samples > 0)
+        WFA_HIP_CHECK(hipMemcpyAsync(samples, d_samples, (size_t)n_samples * 2, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (err != ~0ull) {
+        const long long row = (long long)(err >> 24), field = (long long)((err >> 2) & 0x3fffff);
+        if ((err & 3) == kCsvErrRange)
+            return fail(WFA_E_INVALID, "row %lld field %lld: sample outside the uint16 range", row, field);
+        return fail(WFA_E_INVALID, "row %lld field %lld: not a decimal integer", row, field);
+    }
+    c->csv_filled = true;
     return WFA_OK;
 }
 

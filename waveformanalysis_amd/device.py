@@ -268,18 +268,47 @@ class DeviceSession:
         _lib.check(self._lib.wfa_records_sort(self._h, len(ts), *[_ptr(c) for c in cols], _ptr(order)))
         return order
 
-    def pool_gather(self, src_offset, length, src_pool: np.ndarray, download: bool = True):
-        """Pack wave slices (given in output order) into the resident wave_pool -> (out_offset, pool | None)."""
+    def csv_decode(self, text, delimiter: str = ";", samples_start: int = 7, meta_cols=(0, 1, 2),
+                   download_samples: bool = False) -> dict:
+        """Delimiter-separated integer text (CAEN VX2730 CSV rows, header rows already removed) -> per-row tables.
+
+        Returns meta (n_rows x len(meta_cols) int64), row_offset, n_fields, sample_offset, n_samples and, on request,
+        the ragged uint16 samples; the samples stay on the device as the source of pool_gather(src_pool=None)."""
+        buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else \
+            np.ascontiguousarray(text, dtype=np.uint8)
+        n_rows, n_samples = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.wfa_csv_decode_count(self._h, _ptr(buf), buf.size, ord(delimiter), int(samples_start),
+                                                  C.byref(n_rows), C.byref(n_samples)))
+        n, ns = int(n_rows.value), int(n_samples.value)
+        cols = np.ascontiguousarray(meta_cols, dtype=np.int32)
+        out = {"meta": np.zeros((n, len(cols)), dtype=np.int64), "row_offset": np.zeros(n, dtype=np.int64),
+               "n_fields": np.zeros(n, dtype=np.int32), "sample_offset": np.zeros(n, dtype=np.int64), "n_samples": ns,
+               "samples": np.zeros(ns, dtype=np.uint16) if download_samples else None}
+        _lib.check(self._lib.wfa_csv_decode_fill(self._h, n, len(cols), _ptr(cols), _ptr(out["meta"]),
+                                                 _ptr(out["row_offset"]), _ptr(out["n_fields"]),
+                                                 _ptr(out["sample_offset"]), _ptr(out["samples"]), ns))
+        return out
+
+    def pool_gather(self, src_offset, length, src_pool: np.ndarray | None, download: bool = True,
+                    src_samples: int = 0):
+        """Pack wave slices (given in output order) into the resident wave_pool -> (out_offset, pool | None).
+        src_pool=None with src_samples=n: the source is the samples the last csv_decode left on the device."""
         so = np.ascontiguousarray(src_offset, dtype=np.int64)
         ln = np.ascontiguousarray(length, dtype=np.int32)
+        total = int(np.maximum(ln, 0).astype(np.int64).sum())
+        out_off = np.empty(len(so), dtype=np.int64)
+        out = np.empty(total, dtype=np.uint16) if download else None
+        if src_pool is None:
+            _lib.check(self._lib.wfa_pool_gather(self._h, len(so), _ptr(so), _ptr(ln), None, int(src_samples),
+                                                 _ptr(out_off), _ptr(out), total))
+            self.n_samples = total
+            self.n_records = 0
+            return out_off, out
         src = np.ascontiguousarray(src_pool)
         if src.dtype == np.int16:
             src = src.view(np.uint16)  # _clip_wave_to_uint16: astype(uint16) keeps the bit pattern
         if src.dtype != np.uint16 or src.ndim != 1:
             raise ValueError("src_pool must be a flat uint16 / int16 array")
-        total = int(np.maximum(ln, 0).astype(np.int64).sum())
-        out_off = np.empty(len(so), dtype=np.int64)
-        out = np.empty(total, dtype=np.uint16) if download else None
         _lib.check(self._lib.wfa_pool_gather(self._h, len(so), _ptr(so), _ptr(ln), _ptr(src), src.size, _ptr(out_off),
                                              _ptr(out), total))
         self.n_samples = total

@@ -232,5 +232,144 @@ def build_records_from_v1725_files(file_paths, dt_ns: int, session=None) -> Reco
     return merge_records_parts(parts, sess)
 
 
+# ---- CAEN VX2730 CSV (utils/formats/vx2730.py) ------------------------------------------------------------------
+VX2730_DELIMITER = ";"
+VX2730_SAMPLES_START = 7          # BOARD;CHANNEL;TIMETAG;ENERGY;ENERGYSHORT;FLAGS;PROBE_CODE;samples...
+VX2730_BASELINE_COLUMNS = (7, 47)  # VX2730_SPEC: the first 40 samples (vx2730.py:90-93)
+
+
+def _looks_like_vx2730_header(line: bytes) -> bool:
+    fields = [f.strip().upper() for f in line.decode("utf-8", errors="ignore").strip().split(VX2730_DELIMITER)]
+    return len(fields) >= 3 and tuple(fields[:3]) == ("BOARD", "CHANNEL", "TIMETAG")
+
+
+def vx2730_skiprows(data: bytes, is_first_file: bool) -> int:
+    """vx2730.py:165-191 `_resolve_skiprows`: a header in the first or second line wins; otherwise the first file of a
+    channel carries the legacy two header rows and the others none."""
+    first_end = data.find(b"\n")
+    first = data if first_end < 0 else data[: first_end + 1]
+    if _looks_like_vx2730_header(first):
+        return 1
+    if first_end >= 0:
+        second_end = data.find(b"\n", first_end + 1)
+        second = data[first_end + 1 :] if second_end < 0 else data[first_end + 1 : second_end + 1]
+        if second and _looks_like_vx2730_header(second):
+            return 2
+    return 2 if is_first_file else 0
+
+
+def _strip_rows(data: bytes, n: int) -> bytes:
+    pos = 0
+    for _ in range(n):
+        nxt = data.find(b"\n", pos)
+        if nxt < 0:
+            return b""
+        pos = nxt + 1
+    return data[pos:]
+
+
+def _baseline_window(baseline_samples, samples_start: int, baseline_start: int, baseline_end: int) -> tuple[int, int]:
+    """records_builder.py:53-105: None -> the adapter's columns; int n -> the first n samples; (s, e) -> samples[s:e]
+    (same validation messages)."""
+    if isinstance(baseline_samples, list):
+        baseline_samples = tuple(baseline_samples)
+    if baseline_samples is None:
+        return baseline_start, baseline_end
+    if isinstance(baseline_samples, tuple):
+        if len(baseline_samples) != 2:
+            raise ValueError("baseline_samples tuple must have 2 elements (start, end), "
+                             f"got {len(baseline_samples)}")
+        s0, s1 = baseline_samples
+        if not isinstance(s0, int) or not isinstance(s1, int):
+            raise TypeError("baseline_samples tuple elements must be int, "
+                            f"got ({type(s0).__name__}, {type(s1).__name__})")
+        if s0 < 0 or s1 < 0:
+            raise ValueError(f"baseline_samples indices must be non-negative, got ({s0}, {s1})")
+        if s0 >= s1:
+            raise ValueError(f"baseline_samples start must be less than end, got ({s0}, {s1})")
+        return samples_start + s0, samples_start + s1
+    if isinstance(baseline_samples, int):
+        if baseline_samples <= 0:
+            raise ValueError(f"baseline_samples must be positive, got {baseline_samples}")
+        return baseline_start, baseline_start + int(baseline_samples)
+    raise TypeError("baseline_samples must be int or tuple (start, end), "
+                    f"got {type(baseline_samples).__name__}")
+
+
+def build_records_from_vx2730_files(raw_files, default_dt_ns: int = 1, baseline_samples=None, epoch_ns=None,
+                                    session=None) -> RecordsBundle:
+    """`build_records_from_raw_files(raw_files, adapter_name="vx2730", ...)` (records_builder.py:524-642, 834-867;
+    per file `_build_records_part_from_raw_array` 212-302): raw_files is a list of per-channel file lists.
+
+    The text of all files goes to the GPU in one piece (header rows cut off on the host), is decoded there
+    (wfa_csv_decode_*), the records are ordered with the device sort and the decoded samples are packed into the
+    final wave_pool without leaving the device; the baselines are means over the packed pool.  The reference sorts
+    every file's part and heap-merges the parts with (part, row) as tie-break, which is the stable sort of all rows
+    in (channel list, file, row) order -- one sort here."""
+    import os
+
+    b0, b1 = _baseline_window(baseline_samples, VX2730_SAMPLES_START, *VX2730_BASELINE_COLUMNS)
+    chunks, file_rows_base, file_channel = [], [], []
+    total = 0
+    for channel_idx, files in enumerate(raw_files or []):
+        for k, path in enumerate(files or []):
+            if not os.path.exists(path) or os.path.getsize(path) == 0:   # the reader skips both
+                continue
+            with open(path, "rb") as fh:
+                data = fh.read()
+            body = _strip_rows(data, vx2730_skiprows(data, is_first_file=(k == 0)))
+            if not body:
+                continue
+            if not body.endswith(b"\n"):
+                body += b"\n"
+            chunks.append(body)
+            file_rows_base.append(total)
+            file_channel.append(channel_idx)
+            total += len(body)
+    if not chunks:
+        return _empty()
+    if total >= 2**31:
+        raise ValueError(f"{total} bytes of CSV text; one device decode call takes < 2^31 bytes -- build the run in "
+                         "several calls and merge_records_parts the results")
+    sess = _session(session)
+    dec = sess.csv_decode(b"".join(chunks), VX2730_DELIMITER, VX2730_SAMPLES_START, (0, 1, 2))
+    keep = dec["n_fields"] > 0            # blank lines
+    file_of = np.searchsorted(np.asarray(file_rows_base, dtype=np.int64), dec["row_offset"], side="right") - 1
+    nf = dec["n_fields"]
+    for f in range(len(chunks)):          # a file is one 2-D array in the reference: its rows have one width
+        widths = np.unique(nf[(file_of == f) & keep])
+        if len(widths) > 1:
+            raise ValueError(f"CSV file {f} of channel list {file_channel[f]}: rows with {int(widths[0])} and "
+                             f"{int(widths[1])} fields")
+    rows = np.flatnonzero(keep)
+    n = len(rows)
+    if n == 0:
+        return _empty()
+    lengths = np.maximum(nf[rows] - VX2730_SAMPLES_START, 0).astype(np.int32)
+    rec = np.zeros(n, dtype=RECORDS_DTYPE)
+    meta = dec["meta"][rows]
+    rec["timestamp"] = meta[:, 2]                       # TimestampUnit.PICOSECONDS: already ps
+    rec["pid"] = 0
+    rec["board"] = meta[:, 0].astype(np.int16)
+    rec["channel"] = meta[:, 1].astype(np.int16)
+    rec["baseline_upstream"] = np.nan
+    rec["polarity"] = "unknown"
+    rec["dt"] = np.int32(default_dt_ns)
+    rec["trigger_type"] = 0
+    rec["flags"] = np.uint32(0)
+    rec["event_length"] = lengths
+    rec["time"] = rec["timestamp"] // 1000 if epoch_ns is None else np.int64(epoch_ns) + rec["timestamp"] // 1000
+    order = records_sort_order(rec, sess)
+    rec = rec[order]
+    out_off, pool = sess.pool_gather(dec["sample_offset"][rows][order], rec["event_length"], None,
+                                     src_samples=dec["n_samples"])
+    rec["wave_offset"] = out_off
+    rec["record_id"] = np.arange(n, dtype=np.int64)
+    sess.upload_records(rec)
+    rec["baseline"] = sess.baseline_mean(b0 - VX2730_SAMPLES_START, b1 - VX2730_SAMPLES_START)
+    return RecordsBundle(records=rec, wave_pool=pool)
+
+
 __all__ = ["RecordsBundle", "records_sort_order", "build_records_from_st_waveforms", "merge_records_parts",
-           "v1725_index", "build_records_from_v1725_blob", "build_records_from_v1725_files"]
+           "v1725_index", "build_records_from_v1725_blob", "build_records_from_v1725_files",
+           "build_records_from_vx2730_files", "vx2730_skiprows"]
