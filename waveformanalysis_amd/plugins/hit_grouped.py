@@ -20,7 +20,7 @@ class HipHitGroupedPlugin(Plugin):
     """
 
     provides = "hit_grouped"
-    depends_on = ["hit_threshold"]
+    depends_on = []  # dynamic, see resolve_depends_on
     description = "Group hits across channels into event-level coincidence windows (vectorised)."
     version = "0.5.0+hip1"
     save_when = "always"
