@@ -197,6 +197,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         int64_t total = 0;
         const int64_t* d_total = c->scan_blocks.as<int64_t>() + nb;
         RowParams rp{le, re, max_len, sp0.W / 2};
+        if (c->span_ok && !getenv("WFA_ROWS_NO_UNIFORM")) { rp.uni_L = c->span_L; rp.uni_positive = c->span_positive ? 1 : 0; rp.uni_off0 = c->span_off0; }
         {
             // mask bytes of one block's records (+16 for the aligned start), rounded up to 1 KiB
             const int64_t per_rec = ((int64_t)c->max_len + 7 + 63) / 64 * 8 + 8;

@@ -1741,10 +1741,16 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     double baseline = 0.0;
     bool positive = false;
     if (work) {
-        L = rec.len[r];
-        off = rec.off[r];
         baseline = rec.baseline[r];
-        positive = rec.pol[r] == WFA_POL_POSITIVE;
+        if (rp.uni_L > 0) {  // nothing else to wait for before the first chunk load
+            L = rp.uni_L;
+            off = rp.uni_off0 + r * (int64_t)rp.uni_L;
+            positive = rp.uni_positive != 0;
+        } else {
+            L = rec.len[r];
+            off = rec.off[r];
+            positive = rec.pol[r] == WFA_POL_POSITIVE;
+        }
     }
     const int seg_start = start - rp.le > 0 ? start - rp.le : 0;
     const int seg_end = end + rp.re < rp.max_len ? end + rp.re : rp.max_len;
@@ -1764,8 +1770,9 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     // Then the first maximum of sig is the first extremum of y32: a float32 compare per sample
     // instead of a float64 compare chain; sig itself is only needed for the integral.  Both polarities run the
     // same code on t = +-y32 (one xor on the sign bit): sig = sb - f64(t) with sb = +-b, first minimum of t.
-    // The loop body is straight-line (selects, no per-sample branch: the branchy form cost 15 scalar
-    // instructions and two jumps per sample).  A baseline outside the exact range sends the hit to the literal kernel.
+    // Per sample the body is selects only (an earlier form with per-lane branches cost 15 scalar instructions and two
+    // jumps per sample); what remains is one wave-level skip per sample index.  A baseline outside the exact range sends
+    // the hit to the literal kernel.
     const bool y_order = fabs(baseline) < 262144.0;
     if (work && !y_order) need_literal = true;
     const uint32_t sign_mask = positive ? 0x80000000u : 0u;
@@ -1784,16 +1791,10 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
         m = m < 0 ? 0 : (m > c_hi_load ? c_hi_load : m);
         return p16[m];
     };
-    uint4 v = load_round(c_first);
-    for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 6) {
+    auto do_round = [&](int64_t c, const uint4& v) {
         const int64_t mine = c - 1 + q;
         uint32_t E[12];
         E[4] = v.x ^ 0x80008000u; E[5] = v.y ^ 0x80008000u; E[6] = v.z ^ 0x80008000u; E[7] = v.w ^ 0x80008000u;
-        // the scheduler must not lift the next load above these four reads: the compiler cannot count a load that is
-        // in flight across the back-edge and would wait for `vmcnt(0)`, i.e. for the prefetch it has just issued
-        __builtin_amdgcn_sched_barrier(0);
-        v = load_round(c + 6);  // next round's chunk is in flight while this one is evaluated
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             E[k] = dpp_from_prev_lane(0u, E[4 + k]);
@@ -1803,20 +1804,36 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
         sg_chunk_numerators<W>(E, cpm, Z);
         const bool lane_ok = q >= 1 && q <= 6 && mine <= c_last;
         const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
+        // a sample outside the window gets t = +inf: it never wins the extremum and its signal is -inf, clamped to 0
+        const int idx0 = ilo + rel0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int rel = rel0 + j;
-            const bool in = lane_ok && (unsigned)rel < (unsigned)wlen;
+            const bool in = lane_ok && (unsigned)(rel0 + j) < (unsigned)wlen;
             const int y_num = Z[j] + bias_i;
             const int y_chk = in ? y_num : INT32_MAX;
             y_num_min = y_chk < y_num_min ? y_chk : y_num_min;
             const float y32 = (float)((double)y_num * sg.rden);
-            const float t = __uint_as_float(__float_as_uint(y32) ^ sign_mask);
-            const bool better = in && t < ext_t;  // ascending rel: the first extremum is kept
+            // (the compiler branches around this block when no lane of the wave has sample j in its window; forcing a
+            // straight-line loop measured 0.475 ms against 0.456: short hits leave most of a round's slots empty)
+            const float t = in ? __uint_as_float(__float_as_uint(y32) ^ sign_mask) : __builtin_huge_valf();
+            const bool better = t < ext_t;  // ascending index: the first extremum is kept
             ext_t = better ? t : ext_t;
-            ext_i = better ? ilo + rel : ext_i;
-            const double sgn = sb - (double)t;
-            acc.sum += (in && sgn > 0.0) ? sgn : 0.0;
+            ext_i = better ? idx0 + j : ext_i;
+            acc.sum += fmax(sb - (double)t, 0.0);
+        }
+    };
+    // one chunk in flight ahead of the round being evaluated; a ring of 3 (two ahead) measured 0.480 ms against 0.472:
+    // the kernel is bound by instruction issue, not by the latency of its loads
+    {
+        uint4 v = load_round(c_first);
+        for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 6) {
+            const uint4 cur = v;
+            // the scheduler must not lift the next load above the reads of `v`: the compiler cannot count a load that
+            // is in flight across the back-edge and would wait for `vmcnt(0)`, i.e. for the prefetch it has just issued
+            __builtin_amdgcn_sched_barrier(0);
+            v = load_round(c + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            do_round(c, cur);
         }
     }
     need_literal |= y_num_min < guard;

@@ -89,6 +89,10 @@ struct RowParams {
     // count of this pass is read from `n_dev` on the device, nothing is written at or beyond row `cap`
     int64_t cap = 0;
     const int64_t* n_dev = nullptr;
+    // uniform records (span mode): wave_offset = uni_off0 + r * uni_L and one polarity for all, so the row kernel
+    // needs no per-record loads before its first sample chunk (uni_L = 0: read them from the records table)
+    int32_t uni_L = 0, uni_positive = 0;
+    int64_t uni_off0 = 0;
 };
 
 // find_peaks-based hit detector (k_find_peaks): scalar lower bounds only, as the reference plugin passes them
