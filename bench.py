@@ -154,24 +154,47 @@ def main() -> None:
     if dist is not None:
         from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
 
-        try:
-            uid = [DeviceSession.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            sess.rccl_init(rank, world, uid[0])
-            sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)  # warm-up (connection setup)
-            dist.barrier()
-            t0 = time.perf_counter()
-            counts, rows = sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)
-            gather_ms = (time.perf_counter() - t0) * 1e3
-            total_hits = int(counts.sum())
-            if rank == 0:
-                assert rows is not None and len(rows) == total_hits
-        except Exception as exc:  # the exchange is reported separately; the metric does not depend on it
-            gather_note = f"RCCL gather not run: {exc}"
+        # The exchange is reported next to the metric, which does not depend on it: it runs on a watchdog thread so that
+        # a transport that never comes up (the 8-GPU node is not available to the build sessions) cannot take the
+        # measured line with it.
+        import threading
+
+        box: dict = {}
+
+        def exchange() -> None:
+            try:
+                uid = [DeviceSession.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                sess.rccl_init(rank, world, uid[0])
+                sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)  # warm-up (connection setup)
+                dist.barrier()
+                t1 = time.perf_counter()
+                counts, got = sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)
+                box["ms"] = (time.perf_counter() - t1) * 1e3
+                box["total"] = int(counts.sum())
+                box["rows"] = got
+                if rank == 0:
+                    assert got is not None and len(got) == box["total"]
+            except Exception as exc:  # noqa: BLE001
+                box["note"] = f"RCCL gather not run: {exc}"
+
+        th = threading.Thread(target=exchange, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("WFA_BENCH_GATHER_TIMEOUT_S", "120")))
+        if th.is_alive():
+            gather_note = "RCCL gather did not finish within the watchdog time; metric line unaffected"
+            hung = True
+        else:
+            hung = False
+            gather_ms, gather_note = box.get("ms"), box.get("note")
+            rows = box.get("rows")
+            total_hits = box.get("total", n_hits)
+    else:
+        hung = False
 
     # ---- the other per-record kernels of the path, timed once each (not part of the metric) ----------
     extra_ms = {}
-    if rank == 0 and not args.no_features:
+    if rank == 0 and not args.no_features and not hung:
         from waveformanalysis_amd import _lib as L_
 
         from waveformanalysis_amd.event_grouping import group_hit_windows_flat
@@ -197,7 +220,7 @@ def main() -> None:
         sess.profile(False)
 
     grouping = None
-    if rank == 0 and args.grouping:
+    if rank == 0 and args.grouping and not hung:
         from waveformanalysis_amd.event_grouping import group_hit_windows_flat
 
         all_rows = rows if (dist is not None and gather_ms is not None) else sess._fill_hits(n_hits)
@@ -266,7 +289,7 @@ def main() -> None:
             out["gather_note"] = gather_note
         if grouping:
             out["event_grouping"] = grouping
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a 1-GPU-run figure (rank 0, N = 1)
             n_cpu = min(args.cpu_records, len(records))
             cb = cpu_baseline(records, pool, n_cpu)
             cpu_hits = cb.pop("_hits")
@@ -282,6 +305,8 @@ def main() -> None:
                              "int_fields_bit_exact": bool(int_ok), "max_rel_err_float_fields": flt}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if hung:
+        os._exit(0)  # a stuck transport thread would block the teardown; the line is out
     sess.close()
     if dist is not None:
         dist.destroy_process_group()
