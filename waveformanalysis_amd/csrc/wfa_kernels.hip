@@ -2878,10 +2878,7 @@ hipError_t launch_hits(hipStream_t st, int source, bool fused_baseline, const Po
     } else if (source == WFA_SRC_F32) {
         WFA_LAUNCH_HITS(WFA_SRC_F32, false);
     } else {
-        const bool done = false;
-        if (!done) {
-            if (fused_baseline) WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, true); else WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, false);
-        }
+        if (fused_baseline) WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, true); else WFA_LAUNCH_HITS(WFA_SRC_SG_FUSED, false);
     }
 #undef WFA_LAUNCH_HITS
     return hipGetLastError();
