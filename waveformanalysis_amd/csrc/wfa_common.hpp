@@ -30,6 +30,10 @@ int fail(int code, const char* fmt, ...);
 struct DevBuf {
     void* ptr = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;             // owns device memory
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }                    // whatever wfa_ctx_destroy's list misses is still freed
     int ensure(size_t bytes);  // keeps contents only if no growth is needed
     void release();
     template <typename T>
