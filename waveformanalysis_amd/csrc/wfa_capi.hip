@@ -164,28 +164,51 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         mp.bl_start = bl_start; mp.bl_end = fused_bl ? bl_end : bl_start;
         mp.bitmap = c->bitmap.as<uint8_t>();
         mp.rec_nhits = c->rec_nhits.as<int32_t>();
-        if (c->span_ok && c->span_L >= sp0.W && !getenv("WFA_DISABLE_SPAN")) {
+        // views the kernels of this pass read: the uploaded layout, or the padded shadow of it
+        PoolView pvf = pv0;
+        RecView rvf = rv0;
+        const bool padded = c->pad_ok && sg_mask_span16_padded_supported(sp0, c->pad_L) && !getenv("WFA_DISABLE_PAD") &&
+                            !getenv("WFA_DISABLE_SPAN") && !getenv("WFA_DISABLE_SPAN16");
+        if (padded) {
+            const size_t shadow_samples = (size_t)R * c->pad_S;
+            if (!c->shadow_valid) {
+                if ((rc = c->shadow_pool.ensure(shadow_samples * sizeof(uint16_t) + 256))) return rc;
+                if ((rc = c->shadow_off.ensure((size_t)R * sizeof(int64_t)))) return rc;
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(hipMemsetAsync(c->shadow_pool.as<uint8_t>() + shadow_samples * sizeof(uint16_t), 0, 256, c->stream));
+                WFA_HIP_CHECK(launch_pad_rows(c->stream, pv0.u16, c->pad_off0, c->pad_L, c->pad_S, R,
+                                              c->shadow_pool.as<uint16_t>(), c->shadow_off.as<int64_t>()));
+                if ((rc = t.end("k_pad_rows (once per upload)"))) return rc;
+                c->shadow_valid = true;
+            }
+            pvf.u16 = c->shadow_pool.as<uint16_t>();
+            pvf.n = (int64_t)shadow_samples;
+            rvf.off = c->shadow_off.as<int64_t>();
+        }
+        if (padded || (c->span_ok && c->span_L >= sp0.W && !getenv("WFA_DISABLE_SPAN"))) {
             SpanParams sp{};
             sp.off0 = c->span_off0; sp.L = c->span_L; sp.positive = c->span_positive;
+            if (padded) { sp.off0 = 0; sp.L = c->pad_L; sp.S = c->pad_S; sp.positive = c->pad_positive; }
+            const int32_t span_L = sp.L;
             sp.rs = 64;
             sp.n_spans = (R + sp.rs - 1) / sp.rs;
             sp.bm_off0 = 0;
             sp.dbg = getenv("WFA_SPAN_DBG") ? atoi(getenv("WFA_SPAN_DBG")) : 0;
-            sp.bm_stride = ((int64_t)c->span_L + 7 + 63) / 64 * 8 + 8;
+            sp.bm_stride = ((int64_t)span_L + 7 + 63) / 64 * 8 + 8;
             LaunchTimer t(c);
-            if (sg_mask_mfma_supported(sp0, c->span_L) && getenv("WFA_ENABLE_MFMA")) {  // experiment, see DESIGN.md
-                WFA_HIP_CHECK(launch_sg_mask_span_mfma(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+            if (!padded && sg_mask_mfma_supported(sp0, span_L) && getenv("WFA_ENABLE_MFMA")) {  // experiment, see DESIGN.md
+                WFA_HIP_CHECK(launch_sg_mask_span_mfma(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span_mfma<baseline>" : "k_sg_mask_span_mfma"))) return rc;
-            } else if (sg_mask_span16_supported(sp0, c->span_L) && !getenv("WFA_DISABLE_SPAN16")) {
-                WFA_HIP_CHECK(launch_sg_mask_span16(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+            } else if (padded || (sg_mask_span16_supported(sp0, span_L) && !getenv("WFA_DISABLE_SPAN16"))) {
+                WFA_HIP_CHECK(launch_sg_mask_span16(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span16<baseline>" : "k_sg_mask_span16"))) return rc;
             } else {
-                WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pv0, rv0, sp0, mp, sp));
+                WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
             }
         } else {
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_sg_mask(c->stream, fused_bl, c->max_len, pv0, rv0, sp0, mp));
+            WFA_HIP_CHECK(launch_sg_mask(c->stream, fused_bl, c->max_len, pvf, rvf, sp0, mp));
             if ((rc = t.end(fused_bl ? "k_sg_mask<baseline>" : "k_sg_mask"))) return rc;
         }
         {
@@ -197,7 +220,8 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         int64_t total = 0;
         const int64_t* d_total = c->scan_blocks.as<int64_t>() + nb;
         RowParams rp{le, re, max_len, sp0.W / 2};
-        if (c->span_ok && !getenv("WFA_ROWS_NO_UNIFORM")) { rp.uni_L = c->span_L; rp.uni_positive = c->span_positive ? 1 : 0; rp.uni_off0 = c->span_off0; }
+        if (padded) { rp.uni_L = c->pad_L; rp.uni_S = c->pad_S; rp.uni_positive = c->pad_positive ? 1 : 0; rp.uni_off0 = 0; }
+        else if (c->span_ok && !getenv("WFA_ROWS_NO_UNIFORM")) { rp.uni_L = c->span_L; rp.uni_positive = c->span_positive ? 1 : 0; rp.uni_off0 = c->span_off0; }
         {
             // mask bytes of one block's records (+16 for the aligned start), rounded up to 1 KiB
             const int64_t per_rec = ((int64_t)c->max_len + 7 + 63) / 64 * 8 + 8;
@@ -215,19 +239,19 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             rp.n_dev = d_total;
             {
                 LaunchTimer t(c);
-                WFA_HIP_CHECK(launch_hit_runs(c->stream, rv0, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
+                WFA_HIP_CHECK(launch_hit_runs(c->stream, rvf, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
                                               c->rec_out_start.as<int64_t>(), c->hit_desc.as<int4>(), rp));
                 if ((rc = t.end("k_hit_runs"))) return rc;
             }
             {
                 LaunchTimer t(c);
-                WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pv0, rv0, sp0, rp, c->hit_desc.as<int4>(), bound,
+                WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pvf, rvf, sp0, rp, c->hit_desc.as<int4>(), bound,
                                                    c->hit_out.as<uint8_t>()));
                 if ((rc = t.end("k_hit_rows_grp"))) return rc;
             }
             {
                 LaunchTimer t(c);
-                WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pv0, rv0, sp0, rp,
+                WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pvf, rvf, sp0, rp,
                                                       c->hit_desc.as<int4>(), bound, true, c->hit_out.as<uint8_t>()));
                 if ((rc = t.end("k_hit_rows_literal"))) return rc;
             }
@@ -252,19 +276,19 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         if ((rc = c->hit_desc.ensure((size_t)want * sizeof(int4)))) return rc;
         {
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_hit_runs(c->stream, rv0, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
+            WFA_HIP_CHECK(launch_hit_runs(c->stream, rvf, c->bitmap.as<uint8_t>(), c->rec_nhits.as<int32_t>(),
                                           c->rec_out_start.as<int64_t>(), c->hit_desc.as<int4>(), rp));
             if ((rc = t.end("k_hit_runs"))) return rc;
         }
         {
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pv0, rv0, sp0, rp, c->hit_desc.as<int4>(), total,
+            WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pvf, rvf, sp0, rp, c->hit_desc.as<int4>(), total,
                                                c->hit_out.as<uint8_t>()));
             if ((rc = t.end("k_hit_rows_grp"))) return rc;
         }
         {
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pv0, rv0, sp0, rp,
+            WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pvf, rvf, sp0, rp,
                                                   c->hit_desc.as<int4>(), total, true, c->hit_out.as<uint8_t>()));
             if ((rc = t.end("k_hit_rows_literal"))) return rc;
         }
@@ -427,6 +451,8 @@ int wfa_upload_pool_u16(wfa_ctx* c, const uint16_t* pool, int64_t n) {
     c->have_f32 = false;  // a filtered pool belongs to the previous wave_pool
     c->filter_keep = false;
     c->have_records = false;
+    c->shadow_valid = false;
+    c->pad_ok = false;
     return WFA_OK;
 }
 
@@ -489,6 +515,18 @@ int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int3
         c->span_L = len[0];
         c->span_off0 = off[0];
         c->span_positive = pol[0] == WFA_POL_POSITIVE;
+    }
+    // padded shadow layout: uniform, back-to-back records whose length is not a multiple of 16 samples (VX2730: 1500)
+    c->shadow_valid = false;
+    c->pad_ok = R > 0 && c->have_u16 && len[0] >= 32 && (len[0] % 16) != 0;
+    for (int64_t r = 0; c->pad_ok && r < R; ++r)
+        c->pad_ok = len[r] == len[0] && off[r] == off[0] + r * (int64_t)len[0] &&
+                    (pol[r] == WFA_POL_POSITIVE) == (pol[0] == WFA_POL_POSITIVE);
+    if (c->pad_ok) {
+        c->pad_L = len[0];
+        c->pad_S = (len[0] + 15) / 16 * 16;
+        c->pad_off0 = off[0];
+        c->pad_positive = pol[0] == WFA_POL_POSITIVE;
     }
     const size_t n = (size_t)R;
     if ((rc = h2d(c, c->bm_off, bm_off.data(), n * 8))) return rc;

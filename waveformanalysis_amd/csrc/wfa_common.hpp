@@ -119,6 +119,13 @@ struct wfa_ctx {
     int64_t ht_n = -1, ht_groups = 0;
     int ht_kind = 0;  // 1 = event grouping, 2 = hit merge
     int64_t* ht_perm = nullptr;
+    // padded device layout for uniform records whose length is not a multiple of 16 samples (the span16 kernels need
+    // every lane's 16-sample chunk inside one record): a shadow copy of the u16 pool with the records at stride
+    // pad_S = roundup16(L) and the matching offsets column, built on the device the first time a fused pass needs it
+    bool pad_ok = false, pad_positive = false, shadow_valid = false;
+    int32_t pad_L = 0, pad_S = 0;
+    int64_t pad_off0 = 0;
+    wfa::DevBuf shadow_pool, shadow_off;
     // CSV decode (wfa_hits.hip): rows / samples of the last wfa_csv_decode_count pass; the samples stay resident
     int64_t csv_rows = -1, csv_samples = -1, csv_bytes = 0;
     int32_t csv_samples_start = 0;

@@ -813,6 +813,8 @@ int wfa_pool_gather(wfa_ctx* c, int64_t n, const int64_t* src_offset, const int3
     c->have_f32 = false;
     c->filter_keep = false;
     c->have_records = false;
+    c->shadow_valid = false;
+    c->pad_ok = false;
     return WFA_OK;
 }
 

@@ -742,18 +742,20 @@ struct SpanTable {  // per wave, in LDS
 };
 
 // phase 0: lane = record of the span.  Kept out of line so its registers do not add to the tile loop's.
-template <int W, bool FUSED_BASELINE>
+template <int W, bool FUSED_BASELINE, bool PADDED = false>
 __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, const RecView& rec, const SgParams& sg,
                                                       const MaskParams& mp, const int32_t* __restrict__ etab,
                                                       int64_t g_base, int64_t r0, int nrec, int L, bool positive,
-                                                      double bias, SpanTable* __restrict__ tab) {
+                                                      double bias, SpanTable* __restrict__ tab, int S = 0) {
+    // PADDED: record stride S (multiple of 16) > L, the last S - L samples of a record's slot are padding; else S = L
     constexpr int H = W / 2;
+    if (!PADDED) S = L;
     const int lane = lane_id();
     const int64_t r = r0 + lane;
     int zhi = INT32_MIN, zlo = INT32_MIN, eb = 0;
     double baseline = 0.0, thr = 0.0;
     if (lane < nrec) {
-        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * L) >> 3);
+        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * S) >> 3);
         thr = rec.thr[r];
         if (FUSED_BASELINE) {
             const int s0 = mp.bl_start, e0 = mp.bl_end < L ? mp.bl_end : L;
@@ -786,18 +788,32 @@ __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, cons
         uint32_t border_e = 0;
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {  // left edge, then right edge (same registers)
-            const uint4 c0 = side == 0 ? p[0] : p[(L >> 3) - 2];
-            const uint4 c1 = side == 0 ? p[1] : p[(L >> 3) - 1];
-            const uint32_t dw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             int xw[W];
+            if (!PADDED) {  // L % 8 == 0: the first / last 16 samples are two aligned chunks
+                const uint4 c0 = side == 0 ? p[0] : p[(L >> 3) - 2];
+                const uint4 c1 = side == 0 ? p[1] : p[(L >> 3) - 1];
+                const uint32_t dw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const int q = side == 0 ? k : 16 - W + k;  // first W / last W of the 16 samples
-                const int q0 = k, q1 = 16 - W + k;
-                const uint32_t lo = (dw[q0 >> 1] >> (16 * (q0 & 1))) & 0xffffu;
-                const uint32_t hi = (dw[q1 >> 1] >> (16 * (q1 & 1))) & 0xffffu;
-                (void)q;
-                xw[k] = (int)(side == 0 ? lo : hi);
+                for (int k = 0; k < W; ++k) {
+                    const int q0 = k, q1 = 16 - W + k;  // first W / last W of the 16 samples
+                    const uint32_t lo = (dw[q0 >> 1] >> (16 * (q0 & 1))) & 0xffffu;
+                    const uint32_t hi = (dw[q1 >> 1] >> (16 * (q1 & 1))) & 0xffffu;
+                    xw[k] = (int)(side == 0 ? lo : hi);
+                }
+            } else {  // the first 16 samples, or the last 32 of the slot: the last W samples end S - L before its end
+                const int cb = side == 0 ? 0 : (S >> 3) - 4;
+                const uint4 c0 = p[cb], c1 = p[cb + 1];
+                const uint4 c2 = side == 0 ? c0 : p[cb + 2], c3 = side == 0 ? c1 : p[cb + 3];
+                const uint32_t dw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w,
+                                         c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+                const int q_base = side == 0 ? 0 : L - W - cb * 8;
+                for (int k = 0; k < W; ++k) {
+                    const int qk = q_base + k;
+                    uint32_t word = dw[0];
+#pragma unroll
+                    for (int m = 1; m < 16; ++m) word = (qk >> 1) == m ? dw[m] : word;
+                    xw[k] = (int)((word >> (16 * (qk & 1))) & 0xffffu);
+                }
             }
 #pragma unroll 1
             for (int eh = 0; eh < H; ++eh) {
@@ -812,7 +828,7 @@ __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, cons
             }
         }
         if (border_e) {  // rare: float64 reference code decides
-            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * L, L);
+            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * S, L);
             while (border_e) {
                 const int e = __ffs((int)border_e) - 1;
                 border_e &= border_e - 1;
@@ -1017,7 +1033,7 @@ struct Tile16 {
     uint32_t d[8];
 };
 
-template <int W, bool FUSED_BASELINE>
+template <int W, bool FUSED_BASELINE, bool PADDED = false>
 __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolView pool, RecView rec, SgParams sg,
                                                                             MaskParams mp, SpanParams sp) {
     constexpr int H = W / 2;
@@ -1033,6 +1049,9 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
     const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
     const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
     const int L = sp.L;
+    // PADDED: record stride S = roundup16(L), the last S - L (< 16) samples of a slot are padding (shadow layout)
+    const int S = PADDED ? sp.S : L;
+    const int pad = PADDED ? S - L : 0;
     const bool positive = sp.positive != 0;
 
     uint32_t cpm[NP];
@@ -1049,16 +1068,16 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
     for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
         const int64_t r0 = span * sp.rs;
         const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
-        const int64_t g_base = sp.off0 + r0 * L;
+        const int64_t g_base = sp.off0 + r0 * S;
         if (sp.dbg & 8) {  // measurement only: no per-record phase
             tab->zhi[lane] = INT32_MIN; tab->zlo[lane] = INT32_MIN; tab->eb[lane] = 0; tab->nr[lane] = 0;
         } else {
-            span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
-                                           32768.0 * (double)sg.den, tab);
+            span_phase0<W, FUSED_BASELINE, PADDED>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
+                                                   32768.0 * (double)sg.den, tab, S);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-        const int span_samples = nrec * L;             // multiple of 16
+        const int span_samples = nrec * S;             // multiple of 16
         const int T = (sp.dbg & 4) ? 0 : (span_samples + 1023) / 1024;  // dbg 4: no tile loop
         const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
         const int last_pos = span_samples - 16;
@@ -1072,13 +1091,13 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
             x.d[4] = v1.x; x.d[5] = v1.y; x.d[6] = v1.z; x.d[7] = v1.w;
             return x;
         };
-        int rl = (lane * 16) / L;
-        int i0 = lane * 16 - rl * L;  // multiple of 16; a lane's 16 samples never straddle records (L % 16 == 0)
+        int rl = (lane * 16) / S;
+        int i0 = lane * 16 - rl * S;  // multiple of 16; a lane's 16 samples never straddle record slots (S % 16 == 0)
         uint32_t p5 = fillb, p6 = fillb, p7 = fillb;
         uint32_t carry_msb = 0;
         uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
         int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);
-        const int bm_wrap = (int)sp.bm_stride - (L >> 3);
+        const int bm_wrap = (int)sp.bm_stride - (S >> 3);
 
         auto do_tile = [&](int t, const Tile16& cur, const Tile16& nxt) {
             const bool in_span = t * 1024 + lane * 16 < span_samples;
@@ -1103,11 +1122,12 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
             uint64_t any_c = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) { cm[j] = __ballot(Z[j] < zhi); any_c |= cm[j]; }
-            const bool first = i0 == 0, last = i0 == L - 16;
+            const bool first = i0 == 0, last = i0 == S - 16;
             const uint64_t edge_lanes = __ballot(in_span && (first || last));
             uint32_t bits = 0;
             if (any_c != 0 || edge_lanes != 0) {
-                const uint32_t vb = (first ? (0xffffu << H) & 0xffffu : 0xffffu) & (last ? 0xffffu >> H : 0xffffu);
+                // valid bits: not the H edge samples either side (decided in phase 0), not the padding
+                const uint32_t vb = (first ? (0xffffu << H) & 0xffffu : 0xffffu) & (last ? 0xffffu >> (H + pad) : 0xffffu);
                 const int zlo = tab->zlo[rli];
                 // bits from the compare results (the compiler reuses the lane masks of the candidate test);
                 // the band test (Z > zlo) stays on lane masks in scalar registers and only becomes lane
@@ -1128,7 +1148,7 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
                 }
                 if (any_b != 0 && __ballot(border != 0) != 0) {
                     if (border) {  // rare: the reference's float64 arithmetic decides
-                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
+                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * S, L);
                         const double baseline = tab->bl[rli], thr = tab->thr[rli];
                         while (border) {
                             const int j = __ffs((int)border) - 1;
@@ -1141,7 +1161,7 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
                 }
                 if (in_span && (first || last)) {
                     const uint32_t ebr = (uint32_t)tab->eb[rli];
-                    bits |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (16 - H)) & 0xffffu;
+                    bits |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (16 - H - pad)) & 0xffffu;
                 }
                 if (__ballot(bits != 0) != 0) {
                     uint32_t prevb = dpp_from_prev_lane(carry_msb << 15, bits);
@@ -1157,7 +1177,7 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
             p7 = (uint32_t)__builtin_amdgcn_readlane((int)E[10], 63);
             i0 += 1024;
             bm_pos += 128;
-            while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
+            while (i0 >= S) { i0 -= S; ++rl; bm_pos += bm_wrap; }
         };
         // ring of 3 tiles (2 x 2 KiB in flight per wave), unrolled by 3
         Tile16 ra = tile_at(0), rb = tile_at(1), rc;
@@ -1744,7 +1764,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
         baseline = rec.baseline[r];
         if (rp.uni_L > 0) {  // nothing else to wait for before the first chunk load
             L = rp.uni_L;
-            off = rp.uni_off0 + r * (int64_t)rp.uni_L;
+            off = rp.uni_off0 + r * (int64_t)(rp.uni_S ? rp.uni_S : rp.uni_L);
             positive = rp.uni_positive != 0;
         } else {
             L = rec.len[r];
@@ -3114,6 +3134,49 @@ hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const P
     return hipGetLastError();
 }
 
+// uniform records whose length is not a multiple of 16: the same kernel on the padded shadow layout (stride
+// roundup16(L)).  The last chunk of a slot must hold the H right-edge samples: L % 16 >= H.
+bool sg_mask_span16_padded_supported(const SgParams& sg, int32_t L) {
+    return sg.int_ok && (L % 16) != 0 && (L % 16) >= sg.W / 2 && L >= 32 && sg.W >= 5 && sg.W <= 11;
+}
+
+// shadow layout: record r from src[off0 + r * L ...] to dst[r * S ...], padding zeroed; one thread per 8 samples
+__global__ __launch_bounds__(kBlock) void k_pad_rows(const uint16_t* __restrict__ src, int64_t off0, int32_t L, int32_t S,
+                                                     int64_t R, uint16_t* __restrict__ dst, int64_t* __restrict__ dst_off) {
+    const int per_row = S >> 3;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= R * per_row) return;
+    const int64_t r = g / per_row;
+    const int c = (int)(g - r * per_row);
+    const int64_t idx = off0 + r * (int64_t)L + c * 8;
+    const uint16_t* __restrict__ p = src + idx;
+    uint32_t w[4];
+    if (c * 8 + 8 <= L && (idx & 3) == 0) {  // whole chunk inside the record, source 8-byte aligned
+        const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+    } else if (c * 8 + 8 <= L && (idx & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const uint32_t*>(p + 2 * j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = c * 8 + 2 * j;
+            const uint32_t lo = i < L ? p[2 * j] : 0u, hi = i + 1 < L ? p[2 * j + 1] : 0u;
+            w[j] = lo | (hi << 16);
+        }
+    }
+    *reinterpret_cast<uint4*>(dst + r * (int64_t)S + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (c == 0) dst_off[r] = r * (int64_t)S;
+}
+
+hipError_t launch_pad_rows(hipStream_t st, const uint16_t* src, int64_t off0, int32_t L, int32_t S, int64_t R,
+                           uint16_t* dst, int64_t* dst_off) {
+    if (R == 0) return hipSuccess;
+    const int64_t n = R * (S >> 3);
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, src, off0, L, S, R, dst, dst_off);
+    return hipGetLastError();
+}
+
 bool sg_mask_span16_supported(const SgParams& sg, int L) {
     return sg.int_ok && (L % 16) == 0 && L >= 32 && sg.W >= 5 && sg.W <= 11;
 }
@@ -3128,12 +3191,15 @@ hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const Pool
     if (g < 1) g = 1;
     if (g > resident) g = resident;
     const int grid = (int)g;
+#define WFA_SPAN16_LAUNCH(WW, FB, PD) \
+    hipLaunchKernelGGL((k_sg_mask_span16<WW, FB, PD>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp)
 #define WFA_SPAN16(WW)                                                                                              \
     case WW:                                                                                                        \
-        if (fused_baseline)                                                                                         \
-            hipLaunchKernelGGL((k_sg_mask_span16<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp);  \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_sg_mask_span16<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp); \
+        if (sp.S > sp.L) {                                                                                          \
+            if (fused_baseline) WFA_SPAN16_LAUNCH(WW, true, true); else WFA_SPAN16_LAUNCH(WW, false, true);         \
+        } else {                                                                                                    \
+            if (fused_baseline) WFA_SPAN16_LAUNCH(WW, true, false); else WFA_SPAN16_LAUNCH(WW, false, false);       \
+        }                                                                                                           \
         break;
     switch (sg.W) {
         WFA_SPAN16(5)
@@ -3142,6 +3208,7 @@ hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const Pool
         WFA_SPAN16(11)
         default: return hipErrorInvalidValue;
     }
+#undef WFA_SPAN16_LAUNCH
 #undef WFA_SPAN16
     return hipGetLastError();
 }

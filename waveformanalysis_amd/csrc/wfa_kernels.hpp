@@ -78,6 +78,7 @@ struct SpanParams {
     int64_t bm_off0;   // bitmap byte offset of record 0
     int64_t bm_stride; // bitmap bytes per record
     int32_t dbg;       // measurement knobs (0 in production)
+    int32_t S = 0;     // record stride in samples (0 = L: packed records; span16 only: multiple of 16, S - L < 16)
 };
 
 // hit-row pass (k_hit_rows)
@@ -91,7 +92,7 @@ struct RowParams {
     const int64_t* n_dev = nullptr;
     // uniform records (span mode): wave_offset = uni_off0 + r * uni_L and one polarity for all, so the row kernel
     // needs no per-record loads before its first sample chunk (uni_L = 0: read them from the records table)
-    int32_t uni_L = 0, uni_positive = 0;
+    int32_t uni_L = 0, uni_positive = 0, uni_S = 0;  // uni_S: stride in samples (0 = uni_L)
     int64_t uni_off0 = 0;
 };
 
@@ -156,6 +157,9 @@ hipError_t launch_peak_rows(hipStream_t st, int source, const PoolView& pool, co
                             const int64_t* row_start, const double* ips, uint8_t* out, int* err);
 int hit_runs_block();  // records per block of k_hit_runs (sizes its LDS staging)
 bool sg_mask_supported(const SgParams& sg);
+bool sg_mask_span16_padded_supported(const SgParams& sg, int32_t L);
+hipError_t launch_pad_rows(hipStream_t st, const uint16_t* src, int64_t off0, int32_t L, int32_t S, int64_t R,
+                           uint16_t* dst, int64_t* dst_off);
 hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);
 hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
