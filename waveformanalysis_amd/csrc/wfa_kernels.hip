@@ -2491,6 +2491,8 @@ struct SignalAt {
     int use_derivative;
     int rows;  // WFA_PEAK_SIGNAL_ROWS / _ROWS_F64: the stored samples are the waveform (negative-going pulses)
     int L, n;  // samples in the record, samples of the detection signal
+    int64_t off0;  // the record's first sample in the pool
+    PoolView pv;
     // the waveform the height is measured on
     __device__ __forceinline__ double sig(int i) const {
         const float w = SRC == WFA_SRC_RAW ? (float)xu[i] : xf[i];
@@ -2518,6 +2520,8 @@ struct SignalAt {
     }
     __device__ __forceinline__ void bind(const PoolView& pool, const RecView& rec, int64_t r, const PeakParams& pp) {
         const int64_t off = rec.off[r];
+        off0 = off;
+        pv = pool;
         xu = pool.u16 ? pool.u16 + off : nullptr;
         xf = pool.f32 ? pool.f32 + off : nullptr;
         b64 = rec.baseline[r];
@@ -2530,42 +2534,90 @@ struct SignalAt {
     }
 };
 
+// det(i) for i = i_start, i_start + DIR, ... while the visitor returns true and i stays in [0, n).  The samples come
+// in aligned 16-byte chunks (8 uint16, or 2 x 4 float32) and are consumed from registers with static indices: the walks
+// below are pointer chases of up to a whole record per candidate, and with one load per step each step waited for a
+// cache line (5.1 ms per 10^9 samples for k_peak_eval; chunked: see DESIGN.md).  A derivative value needs the sample
+// after it, which is carried from the previous step (DIR < 0) or makes the value one step late (DIR > 0).
+template <int SRC, int DIR, typename F>
+__device__ __forceinline__ void stream_det(const SignalAt<SRC>& S, int i_start, const F& visit) {
+    const int deriv = S.use_derivative;
+    // sample index range this walk reads, in walking order
+    const int k0 = DIR > 0 ? i_start : i_start + deriv;
+    if (k0 < 0 || k0 >= S.L) return;
+    float carry = 0.f;
+    bool have_carry = false, active = true;
+    int64_t c = (S.off0 + k0) >> 3;
+    const int64_t c_lo = S.off0 >> 3, c_hi = (S.off0 + S.L - 1) >> 3;
+    while (active && c >= c_lo && c <= c_hi) {
+        double wd[8];
+        float wf[8];
+        load_chunk<SRC>(S.pv, c, wd, wf);
+        const int kb = (int)(c * 8 - S.off0);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = DIR > 0 ? jj : 7 - jj;
+            const int k = kb + j;
+            const bool in = DIR > 0 ? (k >= k0 && k < S.L) : (k <= k0 && k >= 0);
+            if (active && in) {
+                const float w = wf[j];
+                if (!deriv) {
+                    active = visit(k, S.det_of(w, 0.f));
+                } else if (DIR > 0) {
+                    if (have_carry) active = visit(k - 1, S.det_of(carry, w));
+                    carry = w; have_carry = true;
+                } else {
+                    if (have_carry) active = visit(k, S.det_of(w, carry));
+                    carry = w; have_carry = true;
+                }
+            }
+        }
+        c += DIR;
+    }
+}
+
 // prominence + width of one candidate; false when it fails `prominence` or `width`
+// (scipy _peak_prominences / _peak_widths with wlen = None, rel_height = 0.5)
 template <int SRC>
 __device__ bool peak_passes(const SignalAt<SRC>& S, int peak, const PeakParams& pp, double& left_ip, double& right_ip) {
-    const int n = S.n;
     const double xp = S.det(peak);
-    int i = peak, left_base = peak, right_base = peak;
+    int left_base = peak, right_base = peak;
     double left_min = xp, right_min = xp;
-    while (0 <= i) {
-        const double v = S.det(i);
-        if (!(v <= xp)) break;
+    stream_det<SRC, -1>(S, peak, [&](int i, double v) {
+        if (!(v <= xp)) return false;
         if (v < left_min) { left_min = v; left_base = i; }
-        --i;
-    }
-    i = peak;
-    while (i <= n - 1) {
-        const double v = S.det(i);
-        if (!(v <= xp)) break;
+        return true;
+    });
+    stream_det<SRC, +1>(S, peak, [&](int i, double v) {
+        if (!(v <= xp)) return false;
         if (v < right_min) { right_min = v; right_base = i; }
-        ++i;
-    }
+        return true;
+    });
     const double prom = xp - (left_min > right_min ? left_min : right_min);
     if (!(prom >= pp.pmin)) return false;
     const double hgt = xp - prom * 0.5;  // rel_height = 0.5
-    i = peak;
-    while (left_base < i && hgt < S.det(i)) --i;
-    left_ip = (double)i;
     {
-        const double xi = S.det(i);
-        if (xi < hgt) left_ip += (hgt - xi) / (S.det(i + 1) - xi);
+        // i = peak; while (left_base < i && hgt < x[i]) --i;  then interpolate between x[i] and x[i + 1]
+        int i_fin = peak;
+        double xi = xp, above = xp;
+        stream_det<SRC, -1>(S, peak, [&](int i, double v) {
+            i_fin = i; xi = v;
+            if (left_base < i && hgt < v) { above = v; return true; }
+            return false;
+        });
+        left_ip = (double)i_fin;
+        if (xi < hgt) left_ip += (hgt - xi) / (above - xi);
     }
-    i = peak;
-    while (i < right_base && hgt < S.det(i)) ++i;
-    right_ip = (double)i;
     {
-        const double xi = S.det(i);
-        if (xi < hgt) right_ip -= (hgt - xi) / (S.det(i - 1) - xi);
+        int i_fin = peak;
+        double xi = xp, above = xp;
+        stream_det<SRC, +1>(S, peak, [&](int i, double v) {
+            i_fin = i; xi = v;
+            if (i < right_base && hgt < v) { above = v; return true; }
+            return false;
+        });
+        right_ip = (double)i_fin;
+        if (xi < hgt) right_ip -= (hgt - xi) / (above - xi);
     }
     return right_ip - left_ip >= pp.wmin;
 }
