@@ -2349,14 +2349,29 @@ struct PyNum {
     bool none;
 };
 
-template <typename T, typename LoadF>
-__device__ PyNum find_crossing(const LoadF& at, int lo, int hi, T thr, bool rising, bool interp) {
+template <int SRC, typename T, typename LoadF>
+__device__ PyNum find_crossing(const PoolView& pool, int64_t base, T baseline, const LoadF& at, int lo, int hi, T thr,
+                               bool rising, bool interp) {
     PyNum out{0.0, false, true};
-    // first index (relative to lo) whose value is >= thr (rising) / <= thr (falling)
+    // first index (relative to lo) whose value is >= thr (rising) / <= thr (falling).  The search reads aligned
+    // 16-byte chunks and tests their samples from registers: with one load per step every step waited for memory.
     int idx = -1;
-    for (int i = lo; i < hi; ++i) {
-        const T y = at(i);
-        if (rising ? (y >= thr) : (y <= thr)) { idx = i - lo; break; }
+    {
+        const int64_t g_lo = base + lo, g_hi = base + hi;  // pool positions [g_lo, g_hi)
+        bool found = false;
+        for (int64_t c = g_lo >> 3; !found && c * 8 < g_hi; ++c) {
+            double wd[8];
+            float wf[8];
+            load_chunk<SRC>(pool, c, wd, wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t g = c * 8 + j;
+                if (!found && g >= g_lo && g < g_hi) {
+                    const T y = SRC == WFA_SRC_RAW ? (T)(wd[j] - (double)baseline) : (T)(wf[j] - (float)baseline);
+                    if (rising ? (y >= thr) : (y <= thr)) { idx = (int)(g - g_lo); found = true; }
+                }
+            }
+        }
     }
     if (idx < 0) return out;
     out.none = false;
@@ -2427,10 +2442,11 @@ __global__ __launch_bounds__(128) void k_waveform_width(PoolView pool, int64_t n
     // python float options are weak: thresholds take the dtype of peak_value
     const T thr_rl = peak_value * (T)wp.rise_low, thr_rh = peak_value * (T)wp.rise_high;
     const T thr_fh = peak_value * (T)wp.fall_high, thr_fl = peak_value * (T)wp.fall_low;
-    const PyNum rise_lo = find_crossing<T>(at, 0, peak, thr_rl, true, interp);
-    const PyNum rise_hi = find_crossing<T>(at, 0, peak, thr_rh, true, interp);
-    PyNum fall_hi = find_crossing<T>(at, peak, L, thr_fh, false, interp);
-    PyNum fall_lo = find_crossing<T>(at, peak, L, thr_fl, false, interp);
+    const int64_t base = ri * L;
+    const PyNum rise_lo = find_crossing<SRC, T>(pool, base, baseline, at, 0, peak, thr_rl, true, interp);
+    const PyNum rise_hi = find_crossing<SRC, T>(pool, base, baseline, at, 0, peak, thr_rh, true, interp);
+    PyNum fall_hi = find_crossing<SRC, T>(pool, base, baseline, at, peak, L, thr_fh, false, interp);
+    PyNum fall_lo = find_crossing<SRC, T>(pool, base, baseline, at, peak, L, thr_fl, false, interp);
 
     PyNum rise_s{0.0, false, false}, rise_t{0.0, false, false};
     if (!rise_lo.none && !rise_hi.none) {
