@@ -2725,10 +2725,7 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
         x_prev = x;
     };
     const int64_t c_lo = off >> 3, c_hi = (off + L - 1) >> 3;
-    for (int64_t c = c_lo; c <= c_hi; ++c) {
-        double wd[8];
-        float wf[8];
-        load_chunk<SRC>(pool, c, wd, wf);
+    auto consume = [&](int64_t c, const float (&wf)[8]) {
         const int kb = (int)(c * 8 - off);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -2741,6 +2738,19 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
                 step(k, S.det_of(wf[jj], 0.f));
             }
         }
+    };
+    // the next chunk is requested before the current one is consumed (two buffers, loop unrolled by two so that no
+    // register copy waits for the load); the chunk behind the record's last one is a valid address (pool slack)
+    float wa[8], wb[8];
+    double wd[8];
+    load_chunk<SRC>(pool, c_lo, wd, wa);
+    for (int64_t c = c_lo;;) {
+        load_chunk<SRC>(pool, c + 1, wd, wb);
+        consume(c, wa);
+        if (++c > c_hi) break;
+        load_chunk<SRC>(pool, c + 1, wd, wa);
+        consume(c, wb);
+        if (++c > c_hi) break;
     }
 }
 
