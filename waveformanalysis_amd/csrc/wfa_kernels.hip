@@ -2222,15 +2222,27 @@ __global__ __launch_bounds__(kFeatBlock) void k_width_integral(PoolView pool, Re
     Pairwise pw;
     pw.init(L, (int)(off & 7), &stacks, threadIdx.x);
     if (L > 0) {
-        for (int64_t c = c_lo; c <= c_hi; ++c) {
-            double wd[8];
-            float wf[8];
-            load_chunk<SRC>(pool, c, wd, wf);
-            const int ib = (int)(c * 8 - off);
-#define WFA_WI_SUM(JJ) { const int i = ib + JJ; if (i >= 0 && i < L) pw.feed<JJ>(xval(wd[JJ], wf[JJ])); }
-            WFA_WI_SUM(0) WFA_WI_SUM(1) WFA_WI_SUM(2) WFA_WI_SUM(3) WFA_WI_SUM(4) WFA_WI_SUM(5) WFA_WI_SUM(6) WFA_WI_SUM(7)
-#undef WFA_WI_SUM
+        // two chunk buffers: the next chunk is in flight while the current one is summed
+        double wda[8], wdb[8];
+        float wfa[8], wfb[8];
+#define WFA_WI_SUM(WD, WF, JJ) { const int i = ib + JJ; if (i >= 0 && i < L) pw.feed<JJ>(xval(WD[JJ], WF[JJ])); }
+#define WFA_WI_CHUNK(WD, WF)                                                                                   \
+        {                                                                                                      \
+            const int ib = (int)(c * 8 - off);                                                                 \
+            WFA_WI_SUM(WD, WF, 0) WFA_WI_SUM(WD, WF, 1) WFA_WI_SUM(WD, WF, 2) WFA_WI_SUM(WD, WF, 3)            \
+            WFA_WI_SUM(WD, WF, 4) WFA_WI_SUM(WD, WF, 5) WFA_WI_SUM(WD, WF, 6) WFA_WI_SUM(WD, WF, 7)            \
         }
+        load_chunk<SRC>(pool, c_lo, wda, wfa);
+        for (int64_t c = c_lo;;) {
+            load_chunk<SRC>(pool, c + 1, wdb, wfb);
+            WFA_WI_CHUNK(wda, wfa)
+            if (++c > c_hi) break;
+            load_chunk<SRC>(pool, c + 1, wda, wfa);
+            WFA_WI_CHUNK(wdb, wfb)
+            if (++c > c_hi) break;
+        }
+#undef WFA_WI_CHUNK
+#undef WFA_WI_SUM
     }
     const double q = pw.result();
 
