@@ -280,7 +280,9 @@ int wfa_width_integral(wfa_ctx* ctx, int source, double q_low, double q_high, do
 
 /* ---- measurement ------------------------------------------------------------------------ */
 
-/* When enabled every kernel launch is bracketed by HIP events on the ctx stream. */
+/* on = 1: every kernel launch is bracketed by HIP events on the ctx stream.  on = 2: only the streaming (mask) kernel
+ * of the fused / SG-fused hit pass is -- the pair of events around each of its small follow-up kernels costs about as
+ * much as the gap it measures.  on = 0: off. */
 int wfa_profile_enable(wfa_ctx* ctx, int on);
 int wfa_profile_reset(wfa_ctx* ctx);
 /* idx-th profiled kernel: name (<= name_len), summed milliseconds, launches. Returns

@@ -195,7 +195,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             sp.bm_off0 = 0;
             sp.dbg = getenv("WFA_SPAN_DBG") ? atoi(getenv("WFA_SPAN_DBG")) : 0;
             sp.bm_stride = ((int64_t)span_L + 7 + 63) / 64 * 8 + 8;
-            LaunchTimer t(c);
+            LaunchTimer t(c, true);
             if (!padded && sg_mask_mfma_supported(sp0, span_L) && getenv("WFA_ENABLE_MFMA")) {  // experiment, see DESIGN.md
                 WFA_HIP_CHECK(launch_sg_mask_span_mfma(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span_mfma<baseline>" : "k_sg_mask_span_mfma"))) return rc;
@@ -207,7 +207,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
             }
         } else {
-            LaunchTimer t(c);
+            LaunchTimer t(c, true);
             WFA_HIP_CHECK(launch_sg_mask(c->stream, fused_bl, c->max_len, pvf, rvf, sp0, mp));
             if ((rc = t.end(fused_bl ? "k_sg_mask<baseline>" : "k_sg_mask"))) return rc;
         }
@@ -1011,6 +1011,7 @@ int wfa_profile_enable(wfa_ctx* c, int on) {
     if (!c) return fail(WFA_E_INVALID, "null context");
     if (!on) (void)profile_flush(c);
     c->prof_on = on != 0;
+    c->prof_level = on == 2 ? 2 : (on ? 1 : 0);
     return WFA_OK;
 }
 

@@ -137,6 +137,7 @@ struct wfa_ctx {
     // work runs and resolved (hipEventElapsedTime) when the report is read, so timing adds no host round trip
     // between the kernels of a pass.
     bool prof_on = false;
+    int prof_level = 0;  // 0 off, 1 every launch, 2 dominant kernels only
     std::vector<wfa::ProfEntry> prof;
     struct PendingEvent {
         hipEvent_t e0, e1;
@@ -167,8 +168,10 @@ struct LaunchTimer {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    explicit LaunchTimer(wfa_ctx* ctx) : c(ctx) {
-        if (!c->prof_on) return;
+    // dominant: the kernel the roofline figure is about -- the only one timed at profile level 2, where the event
+    // pairs around the small kernels of a pass would cost as much as the gaps they measure
+    explicit LaunchTimer(wfa_ctx* ctx, bool dominant = false) : c(ctx) {
+        if (!c->prof_on || (c->prof_level == 2 && !dominant)) return;
         e0 = take(c);
         if (e0) (void)hipEventRecord(e0, c->stream);
     }
