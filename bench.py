@@ -121,6 +121,10 @@ def main() -> None:
     def step() -> int:
         return sess.fused_baseline_filter_hits((0, synth.BASELINE_SAMPLES), 2, 2, download=False)
 
+    def step_enqueue() -> None:
+        # the same pass queued without a host round trip: consecutive passes run back to back on the device
+        sess.hits_enqueue(_wfa_lib.SRC_SG_FUSED, (0, synth.BASELINE_SAMPLES), 2, 2)
+
     def sync_all() -> None:
         sess.sync()  # every launch of this rank is on the session's stream
         if dist is not None:
@@ -133,11 +137,11 @@ def main() -> None:
     sess.profile(2)
     sync_all()
     t0 = time.perf_counter()
-    n_hits = 0
     for _ in range(args.steps):
-        n_hits = step()
+        step_enqueue()
     sync_all()
     elapsed = time.perf_counter() - t0
+    n_hits = sess.hits_wait()  # row count of the last pass (already complete)
     prof = sess.profile_report()
     # per-kernel breakdown of a pass: three more passes with every launch timed, outside the timed region
     sess.profile(1)

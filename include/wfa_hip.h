@@ -146,6 +146,17 @@ int wfa_fused_baseline_filter_hits(wfa_ctx* ctx, int32_t bl_start, int32_t bl_en
                                    int32_t left_extension, int32_t right_extension,
                                    int32_t max_len, int64_t* n_hits);
 
+/* The same passes without a host round trip: _enqueue queues the whole pass on the context's stream and returns (the
+ * row kernels are launched for the previous pass's row count + 12 % and read the real count on the device); _wait
+ * blocks for the last enqueued pass and returns its row count, redoing the pass the exact way in the rare case that it
+ * found more rows than that bound.  source = WFA_SRC_RAW / _F32 / _SG_FUSED; the baseline window applies to
+ * WFA_SRC_SG_FUSED only (bl_end <= bl_start: uploaded baselines).  A context's first pass (no previous count) runs to
+ * completion inside _enqueue.  wfa_threshold_hits_fill waits by itself.  (Streaming callers and bench.py use this
+ * pair: consecutive chunks' passes run back to back on the device.) */
+int wfa_hits_enqueue(wfa_ctx* ctx, int source, int32_t bl_start, int32_t bl_end, int32_t left_extension,
+                     int32_t right_extension, int32_t max_len);
+int wfa_hits_wait(wfa_ctx* ctx, int64_t* n_hits);
+
 /* K8 find_peaks-based hit detector, records source (reference: cpu/peak_finding.py:395-614 calling
  * scipy.signal.find_peaks(det, height, distance, prominence, width, threshold) with scalar lower bounds, then
  * _calculate_peak_height 567-614).  source: WFA_SRC_RAW or WFA_SRC_F32.  Two-phase like the threshold hits; rows

@@ -356,3 +356,29 @@ def test_butterworth_sosfiltfilt_bit_exact(sess):
                         {"records": case["records"], "wave_pool": case["wave_pool"]},
                         plugins=[HipWavePoolFilteredPlugin()])
     np.testing.assert_array_equal(ctx.get_data("run", "wave_pool_filtered"), case["wave_pool_filtered"])
+
+
+def test_enqueued_passes_equal_the_waited_ones():
+    """wfa_hits_enqueue / wfa_hits_wait: passes queued without a host round trip give the rows of the blocking call,
+    also when a pass finds more rows than the speculative launch covered (it is redone exactly inside wait)."""
+    rec, pool = synth.make_run(4000, "v1725", cfg=33)
+    rec_in = rec.copy()
+    rec_in["baseline"] = np.nan
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        sess.upload_records(rec_in, 400.0)                       # few hits: a small row bound for what follows
+        few = sess.fused_baseline_filter_hits((0, 40), 2, 2)
+        sess.hits_enqueue(_lib.SRC_SG_FUSED, (0, 40), 2, 2)
+        assert sess.hits_wait() == len(few)
+        sess.upload_records(rec_in, 10.0)                        # many more hits than that bound
+        sess.hits_enqueue(_lib.SRC_SG_FUSED, (0, 40), 2, 2)
+        n = sess.hits_wait()
+        want = sess.fused_baseline_filter_hits((0, 40), 2, 2)
+        assert n == len(want) > 4 * len(few)
+        for _ in range(3):                                       # now within the bound: nothing waits in between
+            sess.hits_enqueue(_lib.SRC_SG_FUSED, (0, 40), 2, 2)
+        got = sess._fill_hits(sess.hits_wait())
+        assert got.tobytes() == want.tobytes()
+        sess.hits_enqueue(_lib.SRC_SG_FUSED, (0, 40), 2, 2)
+        assert sess._fill_hits(len(want)).tobytes() == want.tobytes()   # fill waits by itself

@@ -47,6 +47,8 @@ SIGNATURES = {
     "wfa_threshold_hits_count": (_int, [_p, _int, _i32, _i32, _i32, C.POINTER(_i64)]),
     "wfa_threshold_hits_fill": (_int, [_p, _p, _i64]),
     "wfa_fused_baseline_filter_hits": (_int, [_p, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
+    "wfa_hits_enqueue": (_int, [_p, _int, _i32, _i32, _i32, _i32, _i32]),
+    "wfa_hits_wait": (_int, [_p, C.POINTER(_i64)]),
     "wfa_find_peaks_count": (_int, [_p, _int, _int, _int, _f64, _int, _f64, _i32, _f64, _f64, _int, _i32, C.POINTER(_i64)]),
     "wfa_find_peaks_fill": (_int, [_p, _p, _i64]),
     "wfa_csv_decode_count": (_int, [_p, _p, _i64, _int, _i32, C.POINTER(_i64), C.POINTER(_i64)]),

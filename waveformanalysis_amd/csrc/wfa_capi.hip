@@ -122,12 +122,17 @@ static int need_source(wfa_ctx* c, int source) {
     }
 }
 
+// enqueue_only: when the pass can take the speculative row launch, queue it and return without waiting for the row
+// count (n_hits may be null; wfa_hits_wait delivers it); otherwise the pass runs to completion as usual.
 static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int32_t bl_end,
-                    int32_t le, int32_t re, int32_t max_len, int64_t* n_hits) {
+                    int32_t le, int32_t re, int32_t max_len, int64_t* n_hits, bool enqueue_only = false) {
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = need_source(c, source))) return rc;
-    if (!n_hits) return fail(WFA_E_INVALID, "n_hits is null");
+    if (!n_hits && !enqueue_only) return fail(WFA_E_INVALID, "n_hits is null");
+    int64_t n_hits_local = 0;
+    if (!n_hits) n_hits = &n_hits_local;
+    c->pending = false;
     if (le < 0) le = 0;  // hit_finder.py:124-125
     if (re < 0) re = 0;
     if (max_len <= 0) max_len = c->max_len;
@@ -254,6 +259,13 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
                 WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pvf, rvf, sp0, rp,
                                                       c->hit_desc.as<int4>(), bound, true, c->hit_out.as<uint8_t>()));
                 if ((rc = t.end("k_hit_rows_literal"))) return rc;
+            }
+            if (enqueue_only) {  // the count goes to the pinned word; nobody waits here
+                WFA_HIP_CHECK(hipMemcpyAsync(c->h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+                c->pending = true;
+                c->pend = {source, fused_bl, bl_start, bl_end, le, re, max_len, bound};
+                c->n_hits = -1;
+                return WFA_OK;
             }
             WFA_HIP_CHECK(hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
             WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -402,6 +414,7 @@ int wfa_ctx_create(int device_id, wfa_ctx** out) {
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_total), sizeof(int64_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
         wfa_ctx_destroy(c);
@@ -424,6 +437,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ht) b.release();
+    if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     (void)profile_flush(c);
@@ -733,9 +747,41 @@ int wfa_fused_baseline_filter_hits(wfa_ctx* c, int32_t bl_start, int32_t bl_end,
     return run_hits(c, WFA_SRC_SG_FUSED, bl_end > bl_start, bl_start, bl_end, le, re, max_len, n_hits);
 }
 
+int wfa_hits_enqueue(wfa_ctx* c, int source, int32_t bl_start, int32_t bl_end, int32_t le, int32_t re, int32_t max_len) {
+    return run_hits(c, source, source == WFA_SRC_SG_FUSED && bl_end > bl_start, bl_start, bl_end, le, re, max_len,
+                    nullptr, true);
+}
+
+int wfa_hits_wait(wfa_ctx* c, int64_t* n_hits) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (!n_hits) return fail(WFA_E_INVALID, "n_hits is null");
+    if (c->pending) {
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->pending = false;
+        const int64_t total = *c->h_total;
+        if (total <= c->pend.bound) {
+            c->last_hits = total;
+            c->n_hits = total;
+        } else {  // more rows than the speculative launch covered: the exact route, now
+            c->last_hits = total;
+            const auto p = c->pend;
+            if ((rc = run_hits(c, p.source, p.fused_bl, p.bl_start, p.bl_end, p.le, p.re, p.max_len, n_hits))) return rc;
+            return WFA_OK;
+        }
+    }
+    if (c->n_hits < 0) return fail(WFA_E_STATE, "no hit pass has been run");
+    *n_hits = c->n_hits;
+    return WFA_OK;
+}
+
 int wfa_threshold_hits_fill(wfa_ctx* c, void* out_rows, int64_t n_hits) {
     int rc = use_device(c);
     if (rc) return rc;
+    if (c->pending) {
+        int64_t n = 0;
+        if ((rc = wfa_hits_wait(c, &n))) return rc;
+    }
     if (c->n_hits < 0) return fail(WFA_E_STATE, "no hit pass has been run");
     if (n_hits != c->n_hits)
         return fail(WFA_E_INVALID, "caller expects %lld rows, the pass produced %lld", (long long)n_hits,

@@ -146,6 +146,11 @@ struct wfa_ctx {
     std::vector<PendingEvent> prof_pending;
     std::vector<hipEvent_t> prof_free;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // enqueue-only hit passes (wfa_hits_enqueue / wfa_hits_wait): the row count of the last enqueued pass lands in a
+    // pinned host word; the pass's arguments are kept in case it outgrew its speculative row bound and must be redone
+    int64_t* h_total = nullptr;
+    bool pending = false;
+    struct { int source; bool fused_bl; int32_t bl_start, bl_end, le, re, max_len; int64_t bound; } pend{};
 
     // rccl (opaque, owned by wfa_rccl.hip)
     void* comm = nullptr;

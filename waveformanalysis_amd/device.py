@@ -204,6 +204,17 @@ class DeviceSession:
             int(right_extension), int(max_len), C.byref(n)))
         return self._fill_hits(int(n.value)) if download else int(n.value)
 
+    def hits_enqueue(self, source: int = _lib.SRC_SG_FUSED, baseline_window: tuple[int, int] = (0, 0),
+                     left_extension: int = 2, right_extension: int = 2, max_len: int = 0) -> None:
+        """Queue a hit pass without waiting for it (see wfa_hits_enqueue); hits_wait() / _fill_hits deliver."""
+        _lib.check(self._lib.wfa_hits_enqueue(self._h, int(source), int(baseline_window[0]), int(baseline_window[1]),
+                                              int(left_extension), int(right_extension), int(max_len)))
+
+    def hits_wait(self) -> int:
+        n = C.c_int64(0)
+        _lib.check(self._lib.wfa_hits_wait(self._h, C.byref(n)))
+        return int(n.value)
+
     def find_peaks(self, source: int = _lib.SRC_F32, use_derivative: bool = True, height: float = 30.0,
                    distance: int = 2, prominence: float = 0.7, width: float = 4, threshold: float | None = None,
                    height_method: str = "minmax", height_window_extension: int = 4,
