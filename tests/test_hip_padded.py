@@ -75,3 +75,40 @@ def test_padded_layout_matches_oracle(L, polarity):
         plain, _a, kernels2 = _run(rec_in, pool, fused_baseline, WFA_DISABLE_PAD="1")
         assert not any("k_pad_rows" in k for k in kernels2)
         assert plain.tobytes() == rows.tobytes()                      # the per-record kernels agree byte for byte
+
+
+@pytest.mark.parametrize("L", [1500, 1000, 100, 37, 47])
+def test_padded_materialised_filter_bit_exact(L):
+    """wave_pool_filtered through the span kernel on the shadow layout == scipy's float32 output == the per-record
+    kernel (WFA_DISABLE_PAD), for every window the integer plan covers and for a low pedestal (literal branch)."""
+    rec, pool = synth.make_run(300 if L > 200 else 2000, "vx2730", cfg=70 + L % 50, L=L)
+    rng = np.random.default_rng(L + 1)
+    w = pool.reshape(len(rec), L).astype(np.int32)
+    w[::7] -= 7990                       # records near zero: numerators below the integer guard
+    w[:, -3:] += rng.integers(-40, 40, (len(rec), 3))   # structure in the right edge samples
+    pool = w.clip(0, 16383).astype(np.uint16).reshape(-1)
+    pool = np.concatenate([np.zeros(4, np.uint16), pool])
+    rec = rec.copy()
+    rec["wave_offset"] += 4
+    for W, P in ((11, 2), (7, 3), (15, 4), (5, 2)):
+        want = O.filter_wave_pool(rec, pool, sg_window_size=W, sg_poly_order=P)
+        outs = {}
+        for env in ({}, {"WFA_DISABLE_PAD": "1"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                with DeviceSession(0) as sess:
+                    sess.upload_pool(pool)
+                    sess.upload_records(rec, 10.0)
+                    plan = sess.set_sg_plan(W, P)
+                    sess.profile(True)
+                    outs[bool(env)] = (sess.savgol(), set(sess.profile_report()))
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        got, kernels = outs[False]
+        # windows without an integer plan take the literal float64 kernel in every layout
+        assert any("k_savgol_span<padded>" in k for k in kernels) == bool(plan.int_ok), (W, P, kernels)
+        np.testing.assert_array_equal(got, want, err_msg=f"L={L} W={W}")
+        np.testing.assert_array_equal(outs[True][0], want)
+        assert not any("padded" in k for k in outs[True][1])

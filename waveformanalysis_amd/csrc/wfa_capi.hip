@@ -122,6 +122,22 @@ static int need_source(wfa_ctx* c, int source) {
     }
 }
 
+// padded shadow of the u16 pool (see wfa_ctx::pad_ok): built once per upload, on the device
+static int ensure_shadow(wfa_ctx* c) {
+    if (c->shadow_valid) return WFA_OK;
+    int rc;
+    const size_t shadow_samples = (size_t)c->R * c->pad_S;
+    if ((rc = c->shadow_pool.ensure(shadow_samples * sizeof(uint16_t) + 256))) return rc;
+    if ((rc = c->shadow_off.ensure((size_t)c->R * sizeof(int64_t)))) return rc;
+    LaunchTimer t(c);
+    WFA_HIP_CHECK(hipMemsetAsync(c->shadow_pool.as<uint8_t>() + shadow_samples * sizeof(uint16_t), 0, 256, c->stream));
+    WFA_HIP_CHECK(launch_pad_rows(c->stream, c->pool_u16.as<uint16_t>(), c->pad_off0, c->pad_L, c->pad_S, c->R,
+                                  c->shadow_pool.as<uint16_t>(), c->shadow_off.as<int64_t>()));
+    if ((rc = t.end("k_pad_rows (once per upload)"))) return rc;
+    c->shadow_valid = true;
+    return WFA_OK;
+}
+
 // enqueue_only: when the pass can take the speculative row launch, queue it and return without waiting for the row
 // count (n_hits may be null; wfa_hits_wait delivers it); otherwise the pass runs to completion as usual.
 static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int32_t bl_end,
@@ -175,19 +191,9 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         const bool padded = c->pad_ok && sg_mask_span16_padded_supported(sp0, c->pad_L) && !getenv("WFA_DISABLE_PAD") &&
                             !getenv("WFA_DISABLE_SPAN") && !getenv("WFA_DISABLE_SPAN16");
         if (padded) {
-            const size_t shadow_samples = (size_t)R * c->pad_S;
-            if (!c->shadow_valid) {
-                if ((rc = c->shadow_pool.ensure(shadow_samples * sizeof(uint16_t) + 256))) return rc;
-                if ((rc = c->shadow_off.ensure((size_t)R * sizeof(int64_t)))) return rc;
-                LaunchTimer t(c);
-                WFA_HIP_CHECK(hipMemsetAsync(c->shadow_pool.as<uint8_t>() + shadow_samples * sizeof(uint16_t), 0, 256, c->stream));
-                WFA_HIP_CHECK(launch_pad_rows(c->stream, pv0.u16, c->pad_off0, c->pad_L, c->pad_S, R,
-                                              c->shadow_pool.as<uint16_t>(), c->shadow_off.as<int64_t>()));
-                if ((rc = t.end("k_pad_rows (once per upload)"))) return rc;
-                c->shadow_valid = true;
-            }
+            if ((rc = ensure_shadow(c))) return rc;
             pvf.u16 = c->shadow_pool.as<uint16_t>();
-            pvf.n = (int64_t)shadow_samples;
+            pvf.n = c->R * (int64_t)c->pad_S;
             rvf.off = c->shadow_off.as<int64_t>();
         }
         if (padded || (c->span_ok && c->span_L >= sp0.W && !getenv("WFA_DISABLE_SPAN"))) {
@@ -681,8 +687,20 @@ int wfa_savgol(wfa_ctx* c, float* out) {
     if (c->R > 0) {
         PoolView pv = pool_view(c);
         const SgParams sp0 = sg_params(c);
+        const bool padded = c->pad_ok && c->pad_L >= sp0.W && sg_mask_supported(sp0) && !getenv("WFA_DISABLE_FAST") &&
+                            !getenv("WFA_DISABLE_PAD");
+        if (padded && (rc = ensure_shadow(c))) return rc;
         LaunchTimer t(c);
-        if (c->span_ok && c->span_L >= 16 && c->span_L >= sp0.W && sg_mask_supported(sp0) &&
+        if (padded) {  // uniform records, L % 16 != 0: span kernel reading the padded shadow, writing the packed pool
+            SpanParams sp{};
+            sp.off0 = 0; sp.L = c->pad_L; sp.S = c->pad_S; sp.out_off0 = c->pad_off0; sp.positive = 0;
+            sp.rs = 64;
+            sp.n_spans = (c->R + sp.rs - 1) / sp.rs;
+            pv.u16 = c->shadow_pool.as<uint16_t>();
+            pv.n = c->R * (int64_t)c->pad_S;
+            WFA_HIP_CHECK(launch_savgol_span(c->stream, pv, rec_view(c), sp0, sp, c->pool_f32.as<float>()));
+            if ((rc = t.end("k_savgol_span<padded>"))) return rc;
+        } else if (c->span_ok && c->span_L >= 16 && c->span_L >= sp0.W && sg_mask_supported(sp0) &&
             !getenv("WFA_DISABLE_FAST")) {
             SpanParams sp{};
             sp.off0 = c->span_off0; sp.L = c->span_L; sp.positive = 0;

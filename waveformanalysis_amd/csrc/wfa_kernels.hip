@@ -1200,7 +1200,9 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
 // y = f32(f64(n.x) * (1/den)) (equal to scipy's float32 output for |n.x| >= guard) and
 // stores 32 contiguous bytes.  Numerators below the guard and the 2H edge samples of every record
 // (integer projection rows, literal below their guard) use the float64 code of k_savgol.
-template <int W>
+// PADDED: input = the padded shadow pool (record stride S = roundup16(L), see wfa_capi: ensure_shadow), output = the
+// packed float32 pool (record stride L)
+template <int W, bool PADDED = false>
 __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView rec, SgParams sg, SpanParams sp,
                                                         float* __restrict__ out) {
     constexpr int H = W / 2;
@@ -1214,6 +1216,7 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
     const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
     const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
     const int L = sp.L;
+    const int S = PADDED ? sp.S : L;  // input stride
     uint32_t cpm[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) {
@@ -1229,23 +1232,40 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
     for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
         const int64_t r0 = span * sp.rs;
         const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
-        const int64_t g_base = sp.off0 + r0 * L;
+        const int64_t g_base = sp.off0 + r0 * S;                   // input
+        const int64_t g_out = PADDED ? sp.out_off0 + r0 * L : g_base;  // output
         // ---- edges: lane = record ----
         if (lane < nrec) {
-            const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * L) >> 3);
-            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * L, L);
+            const uint4* __restrict__ p = reinterpret_cast<const uint4*>(pool.u16) + ((g_base + (int64_t)lane * S) >> 3);
+            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)lane * S, L);
 #pragma unroll 1
             for (int side = 0; side < 2; ++side) {
-                const uint4 c0 = side == 0 ? p[0] : p[(L >> 3) - 2];
-                const uint4 c1 = side == 0 ? p[1] : p[(L >> 3) - 1];
-                const uint32_t dw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                 int xw[W];
+                if (!PADDED) {
+                    const uint4 c0 = side == 0 ? p[0] : p[(L >> 3) - 2];
+                    const uint4 c1 = side == 0 ? p[1] : p[(L >> 3) - 1];
+                    const uint32_t dw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    const int q0 = k, q1 = 16 - W + k;
-                    const uint32_t lo = (dw[q0 >> 1] >> (16 * (q0 & 1))) & 0xffffu;
-                    const uint32_t hi = (dw[q1 >> 1] >> (16 * (q1 & 1))) & 0xffffu;
-                    xw[k] = (int)(side == 0 ? lo : hi);
+                    for (int k = 0; k < W; ++k) {
+                        const int q0 = k, q1 = 16 - W + k;
+                        const uint32_t lo = (dw[q0 >> 1] >> (16 * (q0 & 1))) & 0xffffu;
+                        const uint32_t hi = (dw[q1 >> 1] >> (16 * (q1 & 1))) & 0xffffu;
+                        xw[k] = (int)(side == 0 ? lo : hi);
+                    }
+                } else {  // the first 16 samples, or the last 32 of the slot (the last W samples end S - L before its end)
+                    const int cb = side == 0 ? 0 : (S >> 3) - 4;
+                    const uint4 c0 = p[cb], c1 = p[cb + 1];
+                    const uint4 c2 = side == 0 ? c0 : p[cb + 2], c3 = side == 0 ? c1 : p[cb + 3];
+                    const uint32_t dw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w,
+                                             c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+                    const int q_base = side == 0 ? 0 : L - W - cb * 8;
+                    for (int k = 0; k < W; ++k) {
+                        const int qk = q_base + k;
+                        uint32_t word = dw[0];
+#pragma unroll
+                        for (int m = 1; m < 16; ++m) word = (qk >> 1) == m ? dw[m] : word;
+                        xw[k] = (int)((word >> (16 * (qk & 1))) & 0xffffu);
+                    }
                 }
 #pragma unroll 1
                 for (int eh = 0; eh < H; ++eh) {
@@ -1262,10 +1282,10 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-        const int span_samples = nrec * L;
+        const int span_samples = nrec * S;
         const int T = (span_samples + 511) / 512;
         const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
-        float* __restrict__ out_span = out + g_base;
+        float* __restrict__ out_span = out + g_out;
         const int last_chunk_pos = span_samples - 8;
         auto tile_at = [&](int t) {
             int pos = t * 512 + lane * 8;
@@ -1275,8 +1295,8 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
             x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
             return x;
         };
-        int rl = (lane * 8) / L;
-        int i0 = lane * 8 - rl * L;
+        int rl = (lane * 8) / S;
+        int i0 = lane * 8 - rl * S;
         uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;
         auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
             const int pos = t * 512 + lane * 8;
@@ -1306,10 +1326,11 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
                 low |= y_num < guard;
                 y[j] = (float)((double)y_num * sg.rden);
             }
-            const bool first = i0 == 0, last = i0 == L - 8;
+            // chunks that hold right-edge samples: the last one, or with padding the one or two that overlap [L - H, L)
+            const bool first = i0 == 0, last = PADDED ? (i0 + 8 > L - H && i0 < L) : i0 == L - 8;
             if (__ballot(in_span && (low || first || last)) != 0) {
                 if (in_span && low) {  // below the integer guard: scipy's float64 chain, literally
-                    WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rl * L, L);
+                    WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rl * S, L);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         if (Z[j] + bias_i < guard && i0 + j >= H && i0 + j < L - H) y[j] = sg_value_f64(src.xu, L, i0 + j, src.sg);
@@ -1319,21 +1340,41 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
                     for (int j = 0; j < H; ++j) y[j] = s_edge[wv][rl][j];
                 }
                 if (in_span && last) {
+                    if (!PADDED) {
 #pragma unroll
-                    for (int j = 0; j < H; ++j) y[8 - H + j] = s_edge[wv][rl][H + j];
+                        for (int j = 0; j < H; ++j) y[8 - H + j] = s_edge[wv][rl][H + j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int e = i0 + j - (L - H);  // index among the H right-edge samples
+                            if (e >= 0 && e < H) y[j] = s_edge[wv][rl][H + e];
+                        }
+                    }
                 }
             }
-            if (in_span) {
-                float4* dst = reinterpret_cast<float4*>(out_span + pos);
-                dst[0] = make_float4(y[0], y[1], y[2], y[3]);
-                dst[1] = make_float4(y[4], y[5], y[6], y[7]);
+            if (!PADDED) {
+                if (in_span) {
+                    float4* dst = reinterpret_cast<float4*>(out_span + pos);
+                    dst[0] = make_float4(y[0], y[1], y[2], y[3]);
+                    dst[1] = make_float4(y[4], y[5], y[6], y[7]);
+                }
+            } else if (in_span && i0 < L) {  // packed output: record rl of the span, sample i0 ...
+                float* dst = out_span + (int64_t)rl * L + i0;
+                if (i0 + 8 <= L && ((g_out + (int64_t)rl * L + i0) & 3) == 0) {
+                    reinterpret_cast<float4*>(dst)[0] = make_float4(y[0], y[1], y[2], y[3]);
+                    reinterpret_cast<float4*>(dst)[1] = make_float4(y[4], y[5], y[6], y[7]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (i0 + j < L) dst[j] = y[j];
+                }
             }
             p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
             p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
             p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
             p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
             i0 += 512;
-            while (i0 >= L) { i0 -= L; ++rl; }
+            while (i0 >= S) { i0 -= S; ++rl; }
         };
         Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
         int t = 0;
@@ -3177,8 +3218,11 @@ hipError_t launch_savgol_span(hipStream_t st, const PoolView& pool, const RecVie
     if (g < 1) g = 1;
     if (g > 1024) g = 1024;
     const int grid = (int)g;
-#define WFA_SVS(WW) \
-    case WW: hipLaunchKernelGGL((k_savgol_span<WW>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, sp, out); break;
+#define WFA_SVS(WW)                                                                                                  \
+    case WW:                                                                                                         \
+        if (sp.S > sp.L) hipLaunchKernelGGL((k_savgol_span<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, sp, out); \
+        else hipLaunchKernelGGL((k_savgol_span<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, sp, out);   \
+        break;
     switch (sg.W) {
         WFA_SVS(5)
         WFA_SVS(7)

@@ -78,7 +78,8 @@ struct SpanParams {
     int64_t bm_off0;   // bitmap byte offset of record 0
     int64_t bm_stride; // bitmap bytes per record
     int32_t dbg;       // measurement knobs (0 in production)
-    int32_t S = 0;     // record stride in samples (0 = L: packed records; span16 only: multiple of 16, S - L < 16)
+    int32_t S = 0;     // record stride in samples (0 = L: packed records; span16 / savgol_span: multiple of 16, S - L < 16)
+    int64_t out_off0 = 0;  // k_savgol_span on the padded layout: pool position of record 0 in the packed output
 };
 
 // hit-row pass (k_hit_rows)
