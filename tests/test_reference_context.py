@@ -52,7 +52,7 @@ def ref_env(tmp_path, monkeypatch):
 
     sess = OracleSession()
 
-    def resident(context, pool, pool_filtered=None):
+    def resident(context, pool, pool_filtered=None, **_kw):
         sess.pool = pool
         return sess
 

@@ -8,8 +8,10 @@ happens in libwfa_hip.so; nothing here falls back to numpy.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import threading
+import weakref
 
 import numpy as np
 
@@ -69,12 +71,44 @@ class DeviceSession:
         self.max_len = 0
         self._plan: SgPlan | None = None
         self._keep: list = []  # host arrays referenced by in-flight calls
+        # residency: the host array OBJECTS (strong references, compared with `is`) whose contents the device
+        # pools hold.  An address / size / dtype key does not identify contents: a freed temporary's address is
+        # handed to the next same-shaped array.  Every call that changes a device pool resets these.
+        self._res_pool: np.ndarray | None = None
+        self._res_filtered: np.ndarray | None = None
+        self.uploads = 0  # pool uploads performed (tests, measurement)
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self) -> None:
+        self.forget_resident()
         if getattr(self, "_h", None):
             self._lib.wfa_ctx_destroy(self._h)
             self._h = None
+
+    def forget_resident(self) -> None:
+        """The device pools no longer mirror any host array the session knows of."""
+        self._res_pool = None
+        self._res_filtered = None
+
+    def ensure_pool(self, wave_pool: np.ndarray, cacheable: bool = True) -> bool:
+        """Upload `wave_pool` unless this very array object is what the device pool already holds.
+
+        cacheable=False for temporaries (np.ascontiguousarray / astype copies, dense `wave` fields): they are
+        uploaded every time and never remembered.  Returns True when an upload happened."""
+        if cacheable and self._res_pool is wave_pool:
+            return False
+        self.upload_pool(wave_pool)
+        if cacheable:
+            self._res_pool = wave_pool
+        return True
+
+    def ensure_filtered_pool(self, pool_f32: np.ndarray, cacheable: bool = True) -> bool:
+        if cacheable and self._res_filtered is pool_f32:
+            return False
+        self.upload_filtered_pool(pool_f32)
+        if cacheable:
+            self._res_filtered = pool_f32
+        return True
 
     def __enter__(self):
         return self
@@ -101,6 +135,8 @@ class DeviceSession:
             _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
         else:
             raise ValueError(f"wave_pool dtype must be uint16 or float32, got {wave_pool.dtype}")
+        self.forget_resident()
+        self.uploads += 1
         self.n_samples = int(wave_pool.size)
 
     def upload_filtered_pool(self, pool_f32: np.ndarray) -> None:
@@ -108,7 +144,9 @@ class DeviceSession:
         arr = np.ascontiguousarray(pool_f32, dtype=np.float32)
         if self.n_samples and arr.size != self.n_samples:
             raise ValueError(f"wave_pool_filtered has {arr.size} samples, wave_pool has {self.n_samples}")
+        self._res_filtered = None
         _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
+        self.uploads += 1
 
     def upload_records(self, records: np.ndarray, thresholds: np.ndarray | float = 10.0,
                        polarity: np.ndarray | None = None) -> None:
@@ -169,6 +207,7 @@ class DeviceSession:
 
     def savgol(self, download: bool = True) -> np.ndarray | None:
         out = np.empty(self.n_samples, dtype=np.float32) if download else None
+        self._res_filtered = None  # the device float32 pool is this filter's output now
         _lib.check(self._lib.wfa_savgol(self._h, _ptr(out)))
         return out
 
@@ -180,6 +219,7 @@ class DeviceSession:
         if sos.ndim != 2 or sos.shape[1] != 6 or zi.shape != (sos.shape[0], 2):
             raise ValueError("sos must be (n_sections, 6) and zi (n_sections, 2)")
         out = np.empty(self.n_samples, dtype=np.float32) if download else None
+        self._res_filtered = None
         _lib.check(self._lib.wfa_sosfiltfilt(self._h, int(sos.shape[0]), _ptr(sos), _ptr(zi), int(padlen), _ptr(out)))
         return out
 
@@ -309,6 +349,7 @@ class DeviceSession:
         total = int(np.maximum(ln, 0).astype(np.int64).sum())
         out_off = np.empty(len(so), dtype=np.int64)
         out = np.empty(total, dtype=np.uint16) if download else None
+        self.forget_resident()  # the resident wave_pool becomes the packed output
         if src_pool is None:
             _lib.check(self._lib.wfa_pool_gather(self._h, len(so), _ptr(so), _ptr(ln), None, int(src_samples),
                                                  _ptr(out_off), _ptr(out), total))
@@ -451,40 +492,83 @@ class DeviceSession:
 
 # ---- device pool for the streaming dispatcher ----------------------------------------------------
 class DevicePool:
-    """Round-robin pool of sessions: one per (GPU, worker thread).
+    """Sessions for worker threads: chunk k runs on GPU (k mod n_devices) on its own HIP stream.
 
     The reference dispatches chunks to an ExecutorManager thread pool
-    (waveform_analysis/core/plugins/core/streaming.py:740-860); here each worker thread borrows
-    the session bound to it, so chunk k runs on GPU k mod n_devices on its own HIP stream.
+    (waveform_analysis/core/plugins/core/streaming.py:740-860).  Two ways to get a session:
+
+    * `borrow()` -- context manager for short-lived workers (the streaming drivers): takes a session from a free
+      list, creates one while fewer than `max_sessions` are alive, otherwise waits for one to come back.  Executors
+      come and go; the sessions (and their device buffers, stream, events) are reused, so repeated `compute()`
+      calls hold at most `max_sessions` contexts.
+    * `session()` -- the session bound to the calling thread (static plugins on the Context's thread).  The pool keeps
+      only weak references to these: when the thread goes away its session is closed.
     """
 
-    def __init__(self, device_ids: list[int] | None = None):
-        ids = list(device_ids) if device_ids is not None else list(range(max(device_count(), 1)))
+    def __init__(self, device_ids: list[int] | None = None, max_sessions: int | None = None,
+                 session_factory=None):
+        if device_ids is not None:
+            ids = list(device_ids)
+        else:
+            ids = list(range(max(device_count(), 1))) if session_factory is None else [0]
         if not ids:
             raise _lib.WfaError(_lib.WFA_E_HIP, "no HIP device visible")
         self.device_ids = ids
+        self.max_sessions = int(max_sessions) if max_sessions else max(8, 2 * len(ids))
+        self._factory = session_factory or DeviceSession
         self._local = threading.local()
-        self._lock = threading.Lock()
+        self._lock = threading.Condition()
         self._next = 0
-        self._all: list[DeviceSession] = []
+        self._free: list[DeviceSession] = []
+        self._borrowable = 0                       # sessions created for borrow() and still alive
+        self._thread_bound = weakref.WeakSet()     # sessions handed out by session()
+
+    def _new_session(self) -> DeviceSession:
+        dev = self.device_ids[self._next % len(self.device_ids)]
+        self._next += 1
+        return self._factory(dev)
 
     def session(self) -> DeviceSession:
         s = getattr(self._local, "session", None)
         if s is None:
             with self._lock:
-                dev = self.device_ids[self._next % len(self.device_ids)]
-                self._next += 1
-            s = DeviceSession(dev)
+                s = self._new_session()
+                self._thread_bound.add(s)
             self._local.session = s
-            with self._lock:
-                self._all.append(s)
         return s
+
+    @contextlib.contextmanager
+    def borrow(self):
+        with self._lock:
+            while not self._free and self._borrowable >= self.max_sessions:
+                self._lock.wait()
+            if self._free:
+                s = self._free.pop()
+            else:
+                s = self._new_session()
+                self._borrowable += 1
+        try:
+            yield s
+        finally:
+            with self._lock:
+                self._free.append(s)
+                self._lock.notify()
+
+    @property
+    def live_sessions(self) -> int:
+        with self._lock:
+            return self._borrowable + len(self._thread_bound)
 
     def close(self) -> None:
         with self._lock:
-            for s in self._all:
+            for s in self._free:
                 s.close()
-            self._all.clear()
+            self._borrowable -= len(self._free)
+            self._free.clear()
+            for s in list(self._thread_bound):
+                s.close()
+            self._thread_bound.clear()
+        self._local = threading.local()
 
 
 _default_pool: DevicePool | None = None

@@ -8,7 +8,6 @@ Mirrors (does not import) the reference helpers:
 
 from __future__ import annotations
 
-import threading
 import warnings
 from typing import Any
 
@@ -169,36 +168,31 @@ def per_record_channel_option(records: np.ndarray, channel_config: Any, run_id: 
 
 
 # ---- residency: keep the pool of a run on the GPU between plugin calls -----------------------------
-_resident = threading.local()
+def resident_session(context: Any, pool: np.ndarray, pool_filtered: np.ndarray | None = None, *,
+                     cacheable: bool = True) -> DeviceSession:
+    """Session of this thread with `pool` on the device.
 
-
-def _identity(arr: np.ndarray) -> tuple:
-    return (arr.__array_interface__["data"][0], arr.size, arr.dtype.str)
-
-
-def resident_session(context: Any, pool: np.ndarray, pool_filtered: np.ndarray | None = None) -> DeviceSession:
-    """Session of this thread with `pool` uploaded (skipped when the same buffer is resident)."""
+    The upload is skipped only when the session still holds this very array OBJECT (DeviceSession.ensure_pool:
+    strong reference, compared with `is`, dropped by every call that replaces a device pool -- upload_pool,
+    pool_gather, the filters, close).  Pass cacheable=False for temporaries: dense `wave` fields, astype / asarray
+    copies.  Arrays handed out by a Context (`get_data` memoises its results) are the cacheable case."""
     pool_obj = getattr(context, "wfa_device_pool", None) or default_pool()
     sess = pool_obj.session()
-    state = getattr(_resident, "state", None)
-    if state is None or state.get("sess") is not sess:
-        state = {"sess": sess, "pool": None, "filtered": None}
-        _resident.state = state
-    ident = _identity(pool)
-    if state["pool"] != ident:
-        sess.upload_pool(pool)
-        state["pool"] = ident
-        state["filtered"] = None
+    sess.ensure_pool(pool, cacheable=cacheable)
     if pool_filtered is not None:
-        fid = _identity(pool_filtered)
-        if state["filtered"] != fid:
-            sess.upload_filtered_pool(pool_filtered)
-            state["filtered"] = fid
+        sess.ensure_filtered_pool(pool_filtered, cacheable=cacheable)
     return sess
 
 
-def invalidate_residency() -> None:
-    _resident.state = None
+def invalidate_residency(context: Any = None) -> None:
+    """Drop what this thread's session believes to be resident (kept for callers that replace a pool through
+    the session's own methods -- those reset the tags themselves)."""
+    from .. import device as _device
+
+    pool_obj = (getattr(context, "wfa_device_pool", None) if context is not None else None) or _device._default_pool
+    sess = getattr(pool_obj._local, "session", None) if pool_obj is not None else None
+    if sess is not None:
+        sess.forget_resident()
 
 
 SRC_RAW, SRC_F32, SRC_SG_FUSED = _lib.SRC_RAW, _lib.SRC_F32, _lib.SRC_SG_FUSED

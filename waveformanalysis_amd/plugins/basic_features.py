@@ -75,6 +75,6 @@ class HipBasicFeaturesPlugin(Plugin):
             fixed = K.per_record_channel_option(records, channel_config, run_id, "fixed_baseline", None, np.nan)
             if np.all(np.isnan(fixed)):
                 fixed = None
-        sess = K.resident_session(context, pool)
+        sess = K.resident_session(context, pool, cacheable=False)  # temporary of the dense `wave` field
         sess.upload_records(records, polarity=dense.dense_polarity_wave_rule(data))
         return sess.basic_features(source, height_range, area_range, fixed)

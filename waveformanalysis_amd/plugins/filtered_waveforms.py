@@ -69,8 +69,8 @@ class HipFilteredWaveformsPlugin(Plugin):
         pool, source, L = dense.dense_pool(st, "st_waveforms")
         if source != K.SRC_RAW:
             raise ValueError(f"st_waveforms['wave'] must be int16, got {st['wave'].dtype}")
-        sess = K.resident_session(context, pool)
+        sess = K.resident_session(context, pool, cacheable=False)
         filtered = run_filter_groups(sess, dense.dense_records(st, L), groups)
-        K.invalidate_residency()
+        sess.forget_resident()
         output["wave"] = filtered.reshape(len(st), L)
         return output

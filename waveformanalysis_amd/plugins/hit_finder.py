@@ -90,15 +90,16 @@ class HipHitFinderPlugin(Plugin):
             dt_values = K.require_dt_array(records, explicit_dt=explicit_dt, plugin_name="hit", data_name="records")
 
         rec = _records_for_upload(records, dt_values)
+        converted = False
         if pool_name == "wave_pool_filtered":
             if pool.dtype != np.float32:
-                pool = np.asarray(pool, dtype=np.float32)
+                pool, converted = np.asarray(pool, dtype=np.float32), True
             source = K.SRC_F32
         else:
             if pool.dtype != np.uint16:
                 raise ValueError(f"wave_pool must be uint16, got {pool.dtype}")
             source = K.SRC_RAW
-        sess = K.resident_session(context, pool)
+        sess = K.resident_session(context, pool, cacheable=not converted)
         sess.upload_records(rec, np.zeros(len(rec), dtype=np.float64))
         return sess.find_peaks(source, **peak_kw)
 
@@ -122,7 +123,7 @@ class HipHitFinderPlugin(Plugin):
         pool, source, L = dense.dense_pool(data, data_name)
         rec = dense.dense_records(data, L, keep_record_id=True, truncate_to_event_length=True)
         rec["dt"] = dt_values
-        sess = K.resident_session(context, pool)
+        sess = K.resident_session(context, pool, cacheable=False)  # `pool` is a temporary of the dense `wave` field
         sess.upload_records(rec, np.zeros(len(rec), dtype=np.float64))
         return sess.find_peaks(source, dense_rows=True, **peak_kw)
 

@@ -164,15 +164,15 @@ class HipSignalPeaksStreamPlugin(HipStreamingPlugin):
         rec["polarity"] = "negative"
         rec["wave_offset"] = np.arange(n, dtype=np.int64) * L
         rec["event_length"] = L
-        sess = (self.device_pool or getattr(context, "wfa_device_pool", None) or default_pool()).session()
-        sess.upload_pool(pool)
-        sess.upload_records(rec, 0.0)
-        peaks = sess.find_peaks(source, use_derivative=bool(self.use_derivative), height=float(self.height),
-                                distance=int(self.distance), prominence=float(self.prominence), width=float(self.width),
-                                threshold=None if self.threshold is None else float(self.threshold),
-                                height_method=self.height_method, height_window_extension=self.minmax_window_expand,
-                                dense_rows=2)
-        K.invalidate_residency()  # this thread's session no longer holds the run's pool
+        with self._pool(context).borrow() as sess:
+            sess.upload_pool(pool)
+            sess.upload_records(rec, 0.0)
+            peaks = sess.find_peaks(source, use_derivative=bool(self.use_derivative), height=float(self.height),
+                                    distance=int(self.distance), prominence=float(self.prominence),
+                                    width=float(self.width),
+                                    threshold=None if self.threshold is None else float(self.threshold),
+                                    height_method=self.height_method,
+                                    height_window_extension=self.minmax_window_expand, dense_rows=2)
         if len(peaks) == 0:
             return None
         return Chunk(peaks, int(np.min(peaks["timestamp"])), int(np.max(peaks["timestamp"])), run_id=run_id,

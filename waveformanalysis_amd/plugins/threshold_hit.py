@@ -76,9 +76,10 @@ class HipThresholdHitPlugin(Plugin):
             rec = _with_dt(records, dt_values)
 
         if use_filtered and not fused:
-            if pool.dtype != np.float32:
+            converted = pool.dtype != np.float32
+            if converted:
                 pool = np.asarray(pool, dtype=np.float32)
-            sess = K.resident_session(context, pool)
+            sess = K.resident_session(context, pool, cacheable=not converted)
             source = K.SRC_F32
         else:
             if pool.dtype != np.uint16:
@@ -113,7 +114,7 @@ class HipThresholdHitPlugin(Plugin):
             source_lengths = np.full(len(data), L, dtype=np.int64)
         record_lengths = _lengths_from_records(context, run_id, rec["record_id"], source_lengths)
         thresholds = K.per_record_channel_option(rec, channel_config, run_id, "threshold", threshold, threshold)
-        sess = K.resident_session(context, pool)
+        sess = K.resident_session(context, pool, cacheable=False)  # temporary of the dense `wave` field
         sess.upload_records(rec, thresholds)
         if "baseline" not in names:
             if source != K.SRC_RAW:

@@ -65,9 +65,9 @@ class HipWavePoolFilteredPlugin(Plugin):
             i = int(np.flatnonzero(bad)[0])
             raise ValueError("wave_pool_filtered found out-of-bounds wave slice "
                              f"(offset={int(off[i])}, length={int(length[i])}, wave_pool_size={len(wave_pool)})")
-        sess = K.resident_session(context, np.asarray(wave_pool))
-        out = run_filter_groups(sess, _view_records(records), groups)
-        K.invalidate_residency()  # the resident float32 pool now belongs to this output
+        sess = K.resident_session(context, wave_pool if isinstance(wave_pool, np.ndarray) else np.asarray(wave_pool),
+                                  cacheable=isinstance(wave_pool, np.ndarray))
+        out = run_filter_groups(sess, _view_records(records), groups)  # (the filters drop the float32 tag themselves)
         return out
 
 

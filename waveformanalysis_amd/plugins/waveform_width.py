@@ -88,7 +88,7 @@ class HipWaveformWidthPlugin(Plugin):
             row = np.where((record_id >= 0) & (record_id < len(waveform_data)), record_id, -1)
 
         pool, source, L = dense.dense_pool(waveform_data, data_name)
-        sess = K.resident_session(context, pool)
+        sess = K.resident_session(context, pool, cacheable=False)  # temporary of the dense `wave` field
         rows, valid = sess.waveform_width(source, position, row, len(waveform_data), L, rise_low, rise_high,
                                           fall_high, fall_low, float(sampling_rate), interpolation)
         out = rows[valid]

@@ -62,7 +62,7 @@ class HipWaveformWidthIntegralPlugin(Plugin):
                 if name not in (data.dtype.names or ()):
                     raise ValueError(f"no field of name {name}")  # numpy's message for data[i][name]
             dpool, source, L = dense.dense_pool(data, pool_name)
-            sess = K.resident_session(context, dpool)
+            sess = K.resident_session(context, dpool, cacheable=False)
             sess.upload_records(dense.dense_records(data, L), polarity=dense.dense_polarity_wave_rule(data))
             return sess.width_integral(source, q_low, q_high, float(dt))
         if len(records) == 0:

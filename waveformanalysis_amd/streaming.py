@@ -194,6 +194,9 @@ class HipStreamingPlugin:
         if not v.is_valid:
             raise ValueError(f"Chunk boundary violation in {self.provides}: {v.errors}")
 
+    def _pool(self, context: Any = None) -> DevicePool:
+        return self.device_pool or getattr(context, "wfa_device_pool", None) or default_pool()
+
     def _process(self, chunk: Chunk, context: Any, run_id: str, kwargs: dict):
         result = self._postprocess_result(self.compute_chunk(chunk, context, run_id, **kwargs), chunk)
         if result is not None:
@@ -322,14 +325,15 @@ class HipThresholdHitStream(HipStreamingPlugin):
         hi = int((recs["wave_offset"].astype(np.int64) + recs["event_length"]).max())
         sub = recs.copy()
         sub["wave_offset"] -= lo
-        sess = (self.device_pool or default_pool()).session()
-        sess.upload_pool(np.ascontiguousarray(wave_pool[lo:hi]))
-        sess.upload_records(sub, self.threshold)
-        if self.use_filtered:
-            sess.set_sg_plan(*self.sg)
-            hits = sess.threshold_hits(_lib.SRC_SG_FUSED, self.le, self.re, self.max_len)
-        else:
-            hits = sess.threshold_hits(_lib.SRC_RAW, self.le, self.re, self.max_len)
+        # worker threads come and go with every compute(): the session is borrowed for this chunk only
+        with self._pool(context).borrow() as sess:
+            sess.upload_pool(np.ascontiguousarray(wave_pool[lo:hi]))
+            sess.upload_records(sub, self.threshold)
+            if self.use_filtered:
+                sess.set_sg_plan(*self.sg)
+                hits = sess.threshold_hits(_lib.SRC_SG_FUSED, self.le, self.re, self.max_len)
+            else:
+                hits = sess.threshold_hits(_lib.SRC_RAW, self.le, self.re, self.max_len)
         # a record that overlaps the chunk's end (non-strict halo selection) has hits behind it: the result chunk
         # spans every record it was computed from; the driver clips it back to the core range
         end = max(int(chunk.end), int(self._endtime_of(recs, "timestamp").max()) + 1)
