@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Audit of the hand-placed load pipeline of k_sg_runs32 in hipcc's assembly output (-save-temps).
+
+The tile loads are issued from inline asm; hipcc believes their destination registers are written when the statement
+ends.  Between an issue and the counted wait that names the same registers, no other instruction may touch them (a copy
+or spill there would read registers whose loads have not landed), and the kernel must not spill vector registers at all.
+Exit status 1 with the offending lines if that does not hold."""
+import re
+import sys
+
+
+def regs_of(text: str) -> set:
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def main(path: str) -> int:
+    txt = open(path).read()
+    bad = 0
+    n_kernels = 0
+    for fn in re.split(r"\n(?=_ZN3wfa\w+:)", txt):
+        if not fn.startswith("_ZN3wfa11k_sg_runs32"):
+            continue
+        n_kernels += 1
+        name = fn.split(":")[0]
+        m = re.search(r"\.vgpr_spill_count:\s*(\d+)", fn) or re.search(r"; ScratchSize: (\d+)", fn)
+        if m and int(m.group(1)) != 0:
+            print(f"{name}: vector register spills ({m.group(0)})")
+            bad += 1
+        lines = fn.split("\n")
+        i = 0
+        while i < len(lines):
+            if ";;#ASMSTART" in lines[i]:
+                j = i + 1
+                body = []
+                while ";;#ASMEND" not in lines[j]:
+                    body.append(lines[j])
+                    j += 1
+                if any("buffer_load_dwordx4" in b for b in body):
+                    dst = set()
+                    for b in body:
+                        mm = re.search(r"buffer_load_dwordx4\s+(v\[\d+:\d+\])", b)
+                        if mm:
+                            dst |= regs_of(mm.group(1))
+                    # walk forward (straight-line AND across labels in file order) to the next wait asm
+                    k = j + 1
+                    while k < len(lines):
+                        ln = lines[k].strip()
+                        if ";;#ASMSTART" in ln and "s_waitcnt vmcnt" in lines[k + 1]:
+                            break
+                        if ";;#ASMSTART" in ln and any("buffer_load_dwordx4" in x for x in lines[k + 1:k + 8]):
+                            # the other tile's issue: its registers must be disjoint
+                            other = set()
+                            for x in lines[k + 1:k + 8]:
+                                mm = re.search(r"buffer_load_dwordx4\s+(v\[\d+:\d+\])", x)
+                                if mm:
+                                    other |= regs_of(mm.group(1))
+                            if other & dst:
+                                break  # same tile re-issued (loop wrap in file order): stop this walk
+                        if ln and not ln.startswith((";", ".")) and not ln.endswith(":"):
+                            if regs_of(ln.split(";")[0]) & dst:
+                                print(f"{name}: line {k}: `{ln}` touches in-flight registers of the issue at line {i}")
+                                bad += 1
+                        k += 1
+                i = j
+            i += 1
+    if n_kernels == 0:
+        print("no k_sg_runs32 kernel found in", path)
+        return 1
+    print(f"audit_asm_loads: {n_kernels} kernels checked, {bad} problems")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

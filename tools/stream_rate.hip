@@ -88,6 +88,47 @@ __global__ __launch_bounds__(256) void k_skel(const uint16_t* __restrict__ p, si
     if (acc == 0x12345u) out[0] = acc;
 }
 
+
+// D: lane-slot shapes: a lane owns SLOT bytes of every tile (SLOT/16 loads of 16 B at lane * SLOT + 16 k), two tiles
+// loaded at the top of an iteration and consumed one after the other (the k_sg_runs32 shape at SLOT = 64).
+// COAL: the same bytes read fully coalesced instead (load k of a tile covers 1 KiB: lane * 16 + 1024 k).
+template <int SLOT, bool COAL, int VALU_OPS>
+__global__ __launch_bounds__(256) void k_slot(const uint16_t* __restrict__ p, size_t span_bytes, size_t n_spans, unsigned* out) {
+    constexpr int NL = SLOT / 16;
+    constexpr int TILE = 64 * SLOT;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    unsigned acc = 0;
+    const int T = (int)(span_bytes / TILE);
+    for (size_t s = wave; s < n_spans; s += nwaves) {
+        const char* base = reinterpret_cast<const char*>(p) + s * span_bytes;
+        for (int t = 0; t < T; t += 2) {
+            uint4 a[NL], b[NL];
+            const int t1 = t + 1 < T ? t + 1 : t;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) a[k] = *reinterpret_cast<const uint4*>(base + (size_t)t * TILE + (COAL ? lane * 16 + 1024 * k : lane * SLOT + 16 * k));
+#pragma unroll
+            for (int k = 0; k < NL; ++k) b[k] = *reinterpret_cast<const uint4*>(base + (size_t)t1 * TILE + (COAL ? lane * 16 + 1024 * k : lane * SLOT + 16 * k));
+            unsigned x = 0;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) x ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
+            int v = (int)x;
+#pragma unroll
+            for (int k = 0; k < VALU_OPS * NL / 2; ++k) v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, x), __builtin_bit_cast(s2, 0x00030005u + k), v, false);
+            acc += (unsigned)v;
+            x = 0;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) x ^= b[k].x ^ b[k].y ^ b[k].z ^ b[k].w;
+            v = (int)x;
+#pragma unroll
+            for (int k = 0; k < VALU_OPS * NL / 2; ++k) v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, x), __builtin_bit_cast(s2, 0x00030005u + k), v, false);
+            acc += (unsigned)v;
+        }
+    }
+    if (acc == 0x12345u) out[0] = acc;
+}
+
 template <typename F>
 static void timeit(const char* name, double bytes, F launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -130,6 +171,16 @@ int main() {
         SK(3, 160, true, true, 4096) SK(4, 160, true, true, 4096) SK(3, 160, false, true, 4096)
         SK(2, 160, false, true, 4096) SK(3, 160, true, true, 8192) SK(4, 160, true, true, 8192)
         SK(3, 160, false, true, 8192) SK(2, 160, false, true, 8192)
+    }
+    {
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
+        const size_t sbytes = 64 * 800 * 2, ns = bytes / sbytes;   // 102400 B = 25 tiles of 4 KiB
+        const double b2 = (double)ns * sbytes;
+#define SL(SLOT, COAL, V, W) timeit("D slot " #SLOT " B/lane coalesced " #COAL " valu/2KB " #V " waves " #W, b2, [&] { \
+            hipLaunchKernelGGL((k_slot<SLOT, COAL, V>), dim3(W / 4), dim3(256), 0, 0, q, sbytes, ns, out); });
+        SL(64, false, 0, 3072) SL(64, false, 0, 4096) SL(64, true, 0, 3072) SL(64, true, 0, 4096)
+        SL(32, false, 0, 3072) SL(32, false, 0, 4096) SL(32, true, 0, 4096) SL(128, false, 0, 3072) SL(128, true, 0, 3072)
+        SL(64, false, 160, 3072) SL(64, true, 160, 3072) SL(32, false, 160, 4096)
     }
     // 16-record spans (25 KB): 4x as many, shorter streams
     const size_t span16b = 16 * 800 * 2 / 16;

@@ -138,6 +138,178 @@ static int ensure_shadow(wfa_ctx* c) {
     return WFA_OK;
 }
 
+
+// Uniform records (span mode), Savitzky-Golay source: streaming kernel with ordered run events (wfa_stream.hip).
+//   k_sg_runs32 -> scan of the per-span hit counts -> k_runs_to_desc -> row kernels
+// *done = false: the layout / options are outside what that kernel covers, or a span outgrew its event buffer --
+// the caller takes the general route (per-record mask kernel + bitmap).
+static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t bl_end, int32_t le, int32_t re,
+                           int32_t max_len, int64_t* n_hits, bool enqueue_only, bool* done) {
+    *done = false;
+    if (c->no_runs32 || getenv("WFA_DISABLE_RUNS32")) return WFA_OK;
+    const SgParams sp0 = sg_params(c);
+    SpanParams sp{};
+    bool padded = false;
+    if (c->span_ok && c->span_L % 32 == 0) {
+        sp.off0 = c->span_off0; sp.L = c->span_L; sp.S = c->span_L; sp.positive = c->span_positive;
+    } else if (c->pad_ok && c->pad_S % 32 == 0 && !getenv("WFA_DISABLE_PAD")) {
+        padded = true;
+        sp.off0 = 0; sp.L = c->pad_L; sp.S = c->pad_S; sp.positive = c->pad_positive;
+    } else {
+        return WFA_OK;
+    }
+    if (!sg_runs32_supported(sp0, sp.L, sp.S, bl_start, bl_end, fused_bl)) return WFA_OK;
+    int rc;
+    const int64_t R = c->R;
+    sp.rs = 64;
+    sp.n_spans = (R + sp.rs - 1) / sp.rs;
+    const int64_t ns = sp.n_spans;
+    const int64_t nb = scan_blocks_for(ns);
+    if ((rc = c->run_span_off.ensure((size_t)ns * sizeof(int64_t)))) return rc;
+    if ((rc = c->run_span_cnt.ensure((size_t)ns * sizeof(int32_t)))) return rc;
+    if ((rc = c->run_span_row0.ensure((size_t)ns * sizeof(int64_t)))) return rc;
+    if ((rc = c->run_scan_blocks.ensure((size_t)(nb + 1) * sizeof(int64_t)))) return rc;
+    if (c->run_ctrl.cap < 256 + sizeof(RunsCold)) c->run_cold_valid = false;
+    if ((rc = c->run_ctrl.ensure(256 + sizeof(RunsCold)))) return rc;
+
+    PoolView pvf = pool_view(c);
+    RecView rvf = rec_view(c);
+    if (padded) {
+        if ((rc = ensure_shadow(c))) return rc;
+        pvf.u16 = c->shadow_pool.as<uint16_t>();
+        pvf.n = c->R * (int64_t)c->pad_S;
+        rvf.off = c->shadow_off.as<int64_t>();
+    }
+    RowParams rp{le, re, max_len, sp0.W / 2};
+    rp.uni_L = sp.L; rp.uni_S = sp.S == sp.L ? 0 : sp.S; rp.uni_positive = sp.positive ? 1 : 0; rp.uni_off0 = sp.off0;
+    const int64_t* d_total = c->run_scan_blocks.as<int64_t>() + nb;
+    auto* ctrl = c->run_ctrl.as<unsigned long long>();  // [0] event cursor, [1] flags
+
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        // speculative tail (see run_hits): row buffers sized from the previous pass on this context
+        const int64_t held = (int64_t)std::min(c->hit_out.cap / 60, c->hit_desc.cap / sizeof(int4));
+        const int64_t bound = c->last_hits + c->last_hits / 8 + 4096;
+        const bool spec = c->last_hits >= 0 && held >= bound && !getenv("WFA_NO_SPECULATE") && attempt == 0;
+        int64_t ev_want = spec ? 2 * bound : std::max<int64_t>(2 * bound, R * 8 + 4096);
+        if ((int64_t)(c->run_ev.cap / sizeof(uint32_t)) < ev_want)
+            if ((rc = c->run_ev.ensure((size_t)ev_want * sizeof(uint32_t)))) return rc;
+        RunsParams rn{};
+        rn.ev = c->run_ev.as<uint32_t>();
+        rn.ev_cap = (int64_t)(c->run_ev.cap / sizeof(uint32_t));
+        rn.cursor = ctrl;
+        rn.flags = reinterpret_cast<int32_t*>(ctrl + 1);
+        rn.span_off = c->run_span_off.as<int64_t>();
+        rn.span_cnt = c->run_span_cnt.as<int32_t>();
+        WFA_HIP_CHECK(hipMemsetAsync(ctrl, 0, 16, c->stream));
+        RunsArgs ra{};
+        ra.pool = pvf.u16; ra.thr = rvf.thr; ra.baseline = rvf.baseline_rw; ra.R = R;
+        ra.itab = sp0.itab; ra.den = sp0.den; ra.margin = sp0.margin;
+        ra.den_edge = sp0.den_edge; ra.margin_edge = sp0.margin_edge;
+        // sg_plan.py: guard = 8 eps den^2 2^24 + 1 with eps = bound on |scipy's float64 chain - exact rational|; here in
+        // numerator units with a factor 4 of head room (and never below 1e-6)
+        ra.delta = std::max(4.0 * (double)sp0.guard / (8.0 * (double)sp0.den * 16777216.0), 1e-6);
+        ra.dbg = getenv("WFA_RUNS_DBG") ? atoi(getenv("WFA_RUNS_DBG")) : 0;
+        ra.W = sp0.W; ra.L = sp.L; ra.S = sp.S; ra.positive = sp.positive; ra.rs = sp.rs;
+        ra.off0 = sp.off0; ra.n_spans = ns;
+        ra.ev = rn.ev; ra.ev_cap = rn.ev_cap; ra.cursor = rn.cursor; ra.span_off = rn.span_off; ra.span_cnt = rn.span_cnt;
+        ra.flags = rn.flags;
+        ra.cold = reinterpret_cast<const RunsCold*>(ctrl + 32);  // 256 bytes behind the atomically updated words
+        {
+            // what the float64 reference paths read: a device copy next to the control words, refreshed when it changes
+            RunsCold cold{pvf, sp0};
+            if (!c->run_cold_valid || memcmp(&cold, &c->run_cold_host, sizeof(cold)) != 0) {
+                memcpy(c->h_cold, &cold, sizeof(cold));
+                WFA_HIP_CHECK(hipMemcpyAsync(ctrl + 32, c->h_cold, sizeof(cold), hipMemcpyHostToDevice, c->stream));
+                WFA_HIP_CHECK(hipStreamSynchronize(c->stream));  // h_cold may be rewritten by the next pass
+                c->run_cold_host = cold;
+                c->run_cold_valid = true;
+            }
+        }
+        {
+            LaunchTimer t(c, true);
+            WFA_HIP_CHECK(launch_sg_runs32(c->stream, fused_bl, ra));
+            if ((rc = t.end(fused_bl ? "k_sg_runs32<baseline>" : "k_sg_runs32"))) return rc;
+        }
+        {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_scan(c->stream, rn.span_cnt, ns, c->run_scan_blocks.as<int64_t>(),
+                                      c->run_span_row0.as<int64_t>()));
+            if ((rc = t.end("k_scan(span hit counts)"))) return rc;
+        }
+        auto rows = [&](int64_t n_rows) -> int {
+            {
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(launch_runs_to_desc(c->stream, rn, ns, sp.rs, c->run_span_row0.as<int64_t>(), rp.cap,
+                                                  c->hit_desc.as<int4>()));
+                if (int r2 = t.end("k_runs_to_desc")) return r2;
+            }
+            {
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pvf, rvf, sp0, rp, c->hit_desc.as<int4>(), n_rows,
+                                                   c->hit_out.as<uint8_t>()));
+                if (int r2 = t.end("k_hit_rows_grp")) return r2;
+            }
+            {
+                LaunchTimer t(c);
+                WFA_HIP_CHECK(launch_hit_rows_literal(c->stream, WFA_SRC_SG_FUSED, pvf, rvf, sp0, rp,
+                                                      c->hit_desc.as<int4>(), n_rows, true, c->hit_out.as<uint8_t>()));
+                if (int r2 = t.end("k_hit_rows_literal")) return r2;
+            }
+            return WFA_OK;
+        };
+        int64_t total = 0;
+        unsigned long long ctl[2] = {0, 0};
+        if (spec) {
+            rp.cap = bound;
+            rp.n_dev = d_total;
+            if ((rc = rows(bound))) return rc;
+            if (enqueue_only) {  // total, cursor and flags go to the pinned words; nobody waits here
+                WFA_HIP_CHECK(hipMemcpyAsync(c->h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+                WFA_HIP_CHECK(hipMemcpyAsync(c->h_total + 1, ctrl, 16, hipMemcpyDeviceToHost, c->stream));
+                c->pending = true;
+                c->pend = {WFA_SRC_SG_FUSED, fused_bl, bl_start, bl_end, le, re, max_len, bound, true};
+                c->n_hits = -1;
+                *done = true;
+                return WFA_OK;
+            }
+        }
+        WFA_HIP_CHECK(hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipMemcpyAsync(ctl, ctrl, 16, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const int flags = (int)(ctl[1] & 0xffffffffull);
+        if (flags & 1) {  // a span holds more events than a wave buffers: general route for this upload
+            c->no_runs32 = true;
+            return WFA_OK;
+        }
+        if (flags & 2) {  // event buffer too small: the cursor kept counting, size it and stream again
+            const int64_t need = (int64_t)ctl[0] + (int64_t)ctl[0] / 8 + 4096;
+            if ((rc = c->run_ev.ensure((size_t)need * sizeof(uint32_t)))) return rc;
+            c->last_hits = (int64_t)ctl[0] / 2;
+            continue;
+        }
+        c->last_hits = total;
+        if (spec && total <= bound) {
+            c->n_hits = total;
+            *n_hits = total;
+            *done = true;
+            return WFA_OK;
+        }
+        // first pass on this context, or more hits than the guess: exact sizes (with head room for the next pass)
+        rp.cap = 0;
+        rp.n_dev = nullptr;
+        const int64_t want = total + total / 8 + 4096;
+        if ((rc = c->hit_out.ensure((size_t)want * 60))) return rc;
+        if ((rc = c->hit_desc.ensure((size_t)want * sizeof(int4)))) return rc;
+        if ((rc = rows(total))) return rc;
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->n_hits = total;
+        *n_hits = total;
+        *done = true;
+        return WFA_OK;
+    }
+    return fail(WFA_E_NOMEM, "event buffer of the streaming hit pass did not converge");
+}
+
 // enqueue_only: when the pass can take the speculative row launch, queue it and return without waiting for the row
 // count (n_hits may be null; wfa_hits_wait delivers it); otherwise the pass runs to completion as usual.
 static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int32_t bl_end,
@@ -174,6 +346,11 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
     const RecView rv0 = rec_view(c);
     const SgParams sp0 = sg_params(c);
     if (source == WFA_SRC_SG_FUSED && sg_mask_supported(sp0) && !getenv("WFA_DISABLE_FAST")) {
+        {
+            bool done = false;
+            if ((rc = run_hits_runs32(c, fused_bl, bl_start, bl_end, le, re, max_len, n_hits, enqueue_only, &done))) return rc;
+            if (done) return WFA_OK;
+        }
         // A: mask + run counts  ->  scan  ->  B1: run descriptors  ->  B2: rows (final order, no gather)
         if (c->bitmap.cap < (size_t)c->bitmap_bytes) c->bitmap_clean = false;
         if ((rc = c->bitmap.ensure((size_t)c->bitmap_bytes))) return rc;
@@ -269,7 +446,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             if (enqueue_only) {  // the count goes to the pinned word; nobody waits here
                 WFA_HIP_CHECK(hipMemcpyAsync(c->h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
                 c->pending = true;
-                c->pend = {source, fused_bl, bl_start, bl_end, le, re, max_len, bound};
+                c->pend = {source, fused_bl, bl_start, bl_end, le, re, max_len, bound, false};
                 c->n_hits = -1;
                 return WFA_OK;
             }
@@ -420,7 +597,8 @@ int wfa_ctx_create(int device_id, wfa_ctx** out) {
     c->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_total), sizeof(int64_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_total), 4 * sizeof(int64_t) + sizeof(wfa::RunsCold), hipHostMallocDefault);
+    if (e == hipSuccess) c->h_cold = reinterpret_cast<wfa::RunsCold*>(c->h_total + 4);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
         wfa_ctx_destroy(c);
@@ -440,7 +618,9 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                       &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
                         &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.mfma, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
-                      &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows};
+                      &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows,
+                      &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
+                      &c->shadow_pool, &c->shadow_off};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ht) b.release();
     if (c->h_total) (void)hipHostFree(c->h_total);
@@ -563,6 +743,7 @@ int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int3
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->R = R;
     c->max_len = max_len;
+    c->no_runs32 = false;
     c->have_records = true;
     c->n_hits = -1;
     return WFA_OK;
@@ -778,11 +959,13 @@ int wfa_hits_wait(wfa_ctx* c, int64_t* n_hits) {
         WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
         c->pending = false;
         const int64_t total = *c->h_total;
-        if (total <= c->pend.bound) {
+        const bool runs_bad = c->pend.runs32 && (c->h_total[2] & 0xffffffffll) != 0;  // event buffers overflowed
+        if (runs_bad && (c->h_total[2] & 1)) c->no_runs32 = true;
+        if (total <= c->pend.bound && !runs_bad) {
             c->last_hits = total;
             c->n_hits = total;
         } else {  // more rows than the speculative launch covered: the exact route, now
-            c->last_hits = total;
+            c->last_hits = runs_bad ? std::max<int64_t>(total, c->h_total[1] / 2) : total;
             const auto p = c->pend;
             if ((rc = run_hits(c, p.source, p.fused_bl, p.bl_start, p.bl_end, p.le, p.re, p.max_len, n_hits))) return rc;
             return WFA_OK;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "wfa_hip.h"
+#include "wfa_kernels.hpp"
 
 namespace wfa {
 
@@ -104,6 +105,12 @@ struct wfa_ctx {
     wfa::DevBuf hit_out;        // final rows
     wfa::DevBuf bitmap;         // 1 bit per sample, per-record regions (bm_off)
     wfa::DevBuf hit_desc;       // int4 (record, start, end, k) per hit
+    // streaming pass on uniform records (k_sg_runs32): event buffer, per-span tables, control words
+    wfa::DevBuf run_ev, run_span_off, run_span_cnt, run_span_row0, run_scan_blocks, run_ctrl;
+    wfa::RunsCold* h_cold = nullptr;   // pinned staging (lives behind h_total)
+    wfa::RunsCold run_cold_host{};     // what the device copy holds
+    bool run_cold_valid = false;
+    bool no_runs32 = false;   // a span outgrew the event buffer of its wave: this records upload takes the general route
     int64_t n_hits = -1;
     int64_t last_hits = -1;  // hits of the previous fast-path pass on this context (sizes the speculative tail)
 
@@ -150,7 +157,7 @@ struct wfa_ctx {
     // pinned host word; the pass's arguments are kept in case it outgrew its speculative row bound and must be redone
     int64_t* h_total = nullptr;
     bool pending = false;
-    struct { int source; bool fused_bl; int32_t bl_start, bl_end, le, re, max_len; int64_t bound; } pend{};
+    struct { int source; bool fused_bl; int32_t bl_start, bl_end, le, re, max_len; int64_t bound; bool runs32; } pend{};
 
     // rccl (opaque, owned by wfa_rccl.hip)
     void* comm = nullptr;

@@ -10,171 +10,10 @@
 
 #include "wfa_kernels.hpp"
 #include "wfa_numpy.hpp"
+#include "wfa_device.hpp"
 
 namespace wfa {
 
-namespace {
-
-constexpr int kWave = 64;
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = kBlock / kWave;
-#ifndef WFA_SPAN_WAVES
-#define WFA_SPAN_WAVES 4  // waves per SIMD the span kernel is register-budgeted for (6 and 8 measured slower)
-#endif
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
-__device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
-
-__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
-    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ double uniform_f64(double v) {
-    return __longlong_as_double(uniform_i64(__double_as_longlong(v)));
-}
-
-// ---- wave-level reductions (all 64 lanes participate) ---------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, kWave));
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, kWave));
-    return v;
-}
-__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
-}
-// first-occurrence argmax: larger value wins, ties go to the smaller index (np.argmax).
-__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double ov = __shfl_xor(v, m, kWave);
-        int oi = __shfl_xor(idx, m, kWave);
-        bool take = (ov > v) || (ov == v && oi < idx);
-        v = take ? ov : v;
-        idx = take ? oi : idx;
-    }
-}
-
-// ---- Savitzky-Golay, literal float64 evaluation ---------------------------------------------
-// Interior: scipy.ndimage.correlate1d as called by savgol_filter(mode="interp") (reference call
-// site cpu/filtering.py:234-240).  Symmetric branch:  tmp = x[c]*fw[h];
-// for jj=-h..-1: tmp += (x[c+jj] + x[c-jj]) * fw[h+jj];  general branch: tmp = x[c+h]*fw[w-1];
-// for jj=-h..h-1: tmp += x[c+jj]*fw[h+jj].  Edges: the degree-P least-squares polynomial of the
-// first / last w samples evaluated at the edge positions (scipy _fit_edges_polyfit), here as a
-// precomputed projection row.  Result rounded to float32 like scipy's float32 output array.
-struct SgView {
-    int w;         // effective window (0 = copy)
-    int h;         // w / 2
-    int sym;       // correlate1d symmetric branch?
-    const double* fw;
-    const double* el;  // [h][W] rows
-    const double* er;
-    int row;  // row stride (= plan W)
-};
-
-__device__ __forceinline__ SgView sg_view(const SgParams& sg, int L) {
-    SgView v;
-    int w = sg.W < L ? sg.W : L;
-    if ((w & 1) == 0) w -= 1;
-    if (w <= sg.P || w <= 0) {  // cpu/filtering.py:181-195: no-op filter
-        v.w = 0; v.h = 0; v.sym = 1; v.fw = nullptr; v.el = nullptr; v.er = nullptr; v.row = sg.W;
-        return v;
-    }
-    int t = (w - 1) >> 1;
-    const double* base = sg.tab + (int64_t)t * sg.stride;
-    v.w = w; v.h = w >> 1; v.sym = sg.sym[t];
-    v.fw = base; v.el = base + sg.W; v.er = base + sg.W + sg.H * sg.W; v.row = sg.W;
-    return v;
-}
-
-__device__ __forceinline__ float sg_value_f64(const uint16_t* __restrict__ x, int L, int i,
-                                              const SgView& v) {
-    if (v.w == 0) return (float)x[i];
-    const int h = v.h, w = v.w;
-    if (i < h) {
-        const double* e = v.el + i * v.row;
-        double s = 0.0;
-        for (int k = 0; k < w; ++k) s += e[k] * (double)x[k];
-        return (float)s;
-    }
-    if (i >= L - h) {
-        const double* e = v.er + (i - (L - h)) * v.row;
-        const uint16_t* xx = x + (L - w);
-        double s = 0.0;
-        for (int k = 0; k < w; ++k) s += e[k] * (double)xx[k];
-        return (float)s;
-    }
-    const double* fw = v.fw;
-    double tmp;
-    if (v.sym) {
-        tmp = (double)x[i] * fw[h];
-        for (int jj = -h; jj < 0; ++jj)
-            tmp += ((double)x[i + jj] + (double)x[i - jj]) * fw[h + jj];
-    } else {
-        tmp = (double)x[i + h] * fw[w - 1];
-        for (int jj = -h; jj < h; ++jj) tmp += (double)x[i + jj] * fw[h + jj];
-    }
-    return (float)tmp;
-}
-
-// Wave value of sample i of a record, as float64, exactly as the reference consumer sees it:
-// raw uint16 -> float64, filtered float32 -> float64 (records_view.py:229-253, dtype=float64).
-template <int SRC>
-struct WaveSrc {
-    const uint16_t* xu;
-    const float* xf;
-    int L;
-    SgView sg;
-    __device__ __forceinline__ double at(int i) const {
-        if (SRC == WFA_SRC_RAW) return (double)xu[i];
-        if (SRC == WFA_SRC_F32) return (double)xf[i];
-        return (double)sg_value_f64(xu, L, i, sg);
-    }
-    // float32 view (records_view.py:94: wave.astype(float32))
-    __device__ __forceinline__ float at_f32(int i) const {
-        if (SRC == WFA_SRC_RAW) return (float)xu[i];
-        if (SRC == WFA_SRC_F32) return xf[i];
-        return sg_value_f64(xu, L, i, sg);
-    }
-};
-
-template <int SRC>
-__device__ __forceinline__ WaveSrc<SRC> make_src(const PoolView& pool, const SgParams& sg,
-                                                 int64_t off, int L) {
-    WaveSrc<SRC> s;
-    s.xu = pool.u16 ? pool.u16 + off : nullptr;
-    s.xf = pool.f32 ? pool.f32 + off : nullptr;
-    s.L = L;
-    if (SRC == WFA_SRC_SG_FUSED) s.sg = sg_view(sg, L);
-    return s;
-}
-
-// ---- row writers (packed little-endian rows, 4-byte aligned) --------------------------------
-__device__ __forceinline__ void put_i64(uint32_t* row, int dword, int64_t v) {
-    row[dword] = (uint32_t)(uint64_t)v;
-    row[dword + 1] = (uint32_t)((uint64_t)v >> 32);
-}
-__device__ __forceinline__ void put_f32(uint32_t* row, int dword, float v) {
-    row[dword] = __float_as_uint(v);
-}
-__device__ __forceinline__ void put_f64(uint32_t* row, int dword, double v) {
-    put_i64(row, dword, __double_as_longlong(v));
-}
-
-}  // namespace
 
 // =============================================================================================
 // K1: baseline mean  (records_builder.py:243-257)
@@ -407,43 +246,6 @@ __global__ __launch_bounds__(kBlock) void k_hits(PoolView pool, RecView rec, SgP
 //                  y = f32((n . x)/den) exactly as above (float64 chain below the guard),
 //                  float64 signal, first-argmax, integral, and the packed 60-byte row.
 
-typedef short wfa_s2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ int sdot2_acc(uint32_t pair, uint32_t coef, int acc) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(wfa_s2, pair), __builtin_bit_cast(wfa_s2, coef), acc, false);
-}
-// first tap of an accumulator: VOP3P form with an inline 0 addend (hipcc otherwise emits v_mov 0 + v_dot2c)
-__device__ __forceinline__ int sdot2_first(uint32_t pair, uint32_t coef) {
-    int r;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "v"(coef));
-    return r;
-}
-__device__ __forceinline__ uint32_t dpp_from_prev_lane(uint32_t lane0_value, uint32_t v) {
-    // lane i <- lane i-1 ; lane 0 keeps lane0_value (wave_shr:1, bound_ctrl off)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ uint32_t dpp_from_next_lane(uint32_t lane63_value, uint32_t v) {
-    // lane i <- lane i+1 ; lane 63 keeps lane63_value (wave_shl:1)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane63_value, (int)v, 0x130, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
-}
-// Sum over the wave with DPP row shifts / broadcasts only (no LDS crossbar); result is wave-uniform.
-__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8  -> lane 15 of each row = row sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2,3
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ int clamp_to_i32(double v) {
-    return v >= 2147483647.0 ? INT32_MAX : (v <= -2147483648.0 ? INT32_MIN : (int)v);
-}
 
 struct Tile {
     uint32_t d[4];
@@ -480,16 +282,6 @@ __device__ __forceinline__ RecP load_recp(const RecView& rec, int64_t r, bool wa
     return p;
 }
 
-// integer candidate band:  candidate <=> Z < zhi ; certainly masked <=> Z <= zlo
-__device__ __forceinline__ void int_band(bool positive, double b, double thr, double den, double shift,
-                                         int margin, int& zhi, int& zlo) {
-    // negative/unknown: mask <=> y <= b - thr ; positive: mask <=> -y <= -(b + thr)
-    const double tq = positive ? -(b + thr) * den : (b - thr) * den;
-    if (!(tq == tq)) { zhi = INT32_MIN; zlo = INT32_MIN; return; }  // NaN: no hits
-    const double tz = floor(tq) + shift;
-    zhi = clamp_to_i32(tz + (double)margin + 1.0);
-    zlo = clamp_to_i32(tz - (double)margin);
-}
 
 // 8 SG numerators of one lane's chunk from its own dwords and the halo dwords of both neighbours.
 //   E[0..3] = previous chunk, E[4..7] = own, E[8..11] = next  (samples biased by -32768)

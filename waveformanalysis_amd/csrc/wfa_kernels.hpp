@@ -82,6 +82,44 @@ struct SpanParams {
     int64_t out_off0 = 0;  // k_savgol_span on the padded layout: pool position of record 0 in the packed output
 };
 
+// run events of the streaming pass (k_sg_runs32): per span a contiguous block of 32-bit events
+// (record-in-span << 16 | position), start / end alternating, allocated from `cursor` when the span is done
+struct RunsParams {
+    uint32_t* ev;
+    int64_t ev_cap;              // events the buffer holds
+    unsigned long long* cursor;  // events allocated so far (keeps counting beyond ev_cap: the size a redo needs)
+    int64_t* span_off;           // [n_spans] first event of the span
+    int32_t* span_cnt;           // [n_spans] hits (= events / 2) of the span
+    int32_t* flags;              // bit 0: a span outgrew the LDS buffer, bit 1: `ev` too small
+};
+
+// k_sg_runs32: arguments the tile loop keeps in scalar registers, and (by pointer, device-resident) what only the
+// float64 reference paths read
+struct RunsCold {
+    PoolView pool;
+    SgParams sg;
+};
+struct RunsArgs {
+    const uint16_t* pool;   // uint16 pool the records live in (packed, or the padded shadow)
+    const double* thr;      // records.threshold
+    double* baseline;       // records.baseline (read when given, written when estimated in-stream)
+    int64_t R;
+    const int32_t* itab;    // integer SG plan: W numerators, then the 2H edge rows
+    int32_t den, margin;
+    int32_t den_edge, margin_edge;  // edge projection rows: denominator, band half-width
+    double delta;           // numerator units by which scipy's float64 chain may differ from the exact rational
+    int32_t W, L, S, positive, rs;
+    int32_t dbg;            // measurement knobs (WFA_MEASURE builds; 0 in production)
+    int64_t off0, n_spans;
+    uint32_t* ev;
+    int64_t ev_cap;
+    unsigned long long* cursor;
+    int64_t* span_off;
+    int32_t* span_cnt;
+    int32_t* flags;
+    const RunsCold* cold;
+};
+
 // hit-row pass (k_hit_rows)
 struct RowParams {
     int32_t le, re, max_len;
@@ -173,6 +211,10 @@ hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const Pool
 bool sg_mask_mfma_supported(const SgParams& sg, int L);
 hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                     const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
+bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl);
+hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a);
+hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,
+                               const int64_t* span_row0, int64_t cap, int4* desc);
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
                            const int64_t* out_start, int4* desc, const RowParams& rp);
 hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
