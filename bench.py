@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- Gsamples/s of the fused baseline + Savitzky-Golay filter + threshold-hit pass.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--records R] [--preset v1725]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--records R] [--preset v1725|vx2730]
 
-One *step* = one pass of the hot path over one resident chunk: the fused kernel
-(baseline estimate over the first 40 samples, SG(11,2) filter evaluated on the fly, threshold
-hits) + the hit-count scan + the gather into (record, start) order.  Inputs (wave_pool uint16,
-records SoA) are resident in HBM before the timed region; hit rows stay on the device.
+One *step* = one pass of the hot path over one resident chunk: the streaming kernel (baseline estimate over the first 40
+samples, SG(11,2) filter evaluated on the fly, threshold mask -> ordered run events), the scan of the per-span hit
+counts, the descriptor gather and the hit-row kernels.  Inputs (wave_pool uint16, records SoA) are resident in HBM
+before the timed region; hit rows stay on the device.
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  Records shard by channel with no
-data-path collective, so every rank processes its own equally sized shard
-("weak" scaling) and value = all samples / max-over-ranks time.  After the timed region the
-ranks' hits are gathered to rank 0 over RCCL (the event-grouping exchange) and that time is
-reported separately as gather_ms.
+N > 1: one rank per GPU.  Launched either by the driver (`python -m torch.distributed.run ... bench.py --gpus N`, ranks
+read RANK / LOCAL_RANK / WORLD_SIZE) or plainly as `python bench.py --gpus N`: then this process starts the N ranks
+itself as a child `torch.distributed.run` -- before anything in it has touched HIP -- relays their JSON line and exits
+with their status.  Records shard by channel with no data-path collective: every rank processes
+its own equally sized shard ("weak" scaling), value = all samples / max-over-ranks time.  After the timed region the
+ranks' hit rows are gathered to rank 0 over RCCL (the event-grouping exchange), stay on its device, and are grouped
+there (`group_hit_windows`, 100 ns) without a host round trip; `gather_ok` says whether that exchange completed -- if
+it did not, the line is still printed and the process exits non-zero.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit..., plus
-  roofline     achieved = (2*N + 29*R + 60*H) bytes / mean duration of the fused kernel, measured
-               with HIP events on the kernel's own stream inside the timed region; peak 8000 GB/s
-  cpu_baseline the oracle's literal reference loops (scipy savgol per record + per-hit python
-               loop) timed on a bounded slice of the same chunk on this host, single thread
+  roofline     achieved = (2*N + 29*R + 60*H) bytes / mean duration of the streaming kernel, measured with HIP events
+               on the kernel's own stream inside the timed region; peak 8000 GB/s; `frac_pass` = the same bytes over
+               the whole step; `traffic` = HBM bytes per launch from rocprofv3 PMC passes of THIS kernel on THIS
+               workload (profiles/hbm_traffic.json, keyed by kernel | preset | records | L), else null
+  cpu_baseline the oracle's port of the reference loops on a bounded slice of the same chunk on this host: the filter
+               leg on os.cpu_count() threads (the reference's default, cpu/records.py:405-430), hit finding on one
+  end_to_end   HipThresholdHitPlugin.compute on the same chunk from host arrays: H2D + kernels + D2H of the rows
 """
 
 from __future__ import annotations
@@ -26,54 +32,21 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from waveformanalysis_amd import synth  # noqa: E402
-from waveformanalysis_amd.device import DeviceSession  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # dominant (streaming) kernel of the fused pass, by preference: uniform records on the run-event kernel, else the
-# per-record mask kernels
+# bitmap route's mask kernels
 FUSED_KERNELS = ("k_sg_runs32<baseline>", "k_sg_mask_span16<baseline>", "k_sg_mask<baseline>")
+EXIT_GATHER_FAILED = 3
 
 
-def cpu_baseline(records: np.ndarray, pool: np.ndarray, n_records: int) -> dict:
-    """Time the oracle (port of the reference loops) on the first n_records of the chunk."""
-    from oracle import wfa_oracle as O
-
-    L = int(records["event_length"][0])
-    rec = records[:n_records].copy()
-    sub = pool[: n_records * L]
-    t0 = time.perf_counter()
-    rec["baseline"] = O.baseline_mean(sub.reshape(-1, L), 0, synth.BASELINE_SAMPLES)
-    filt = O.filter_wave_pool(rec, sub)  # per-record scipy savgol_filter, as records.py:368-438
-    hits = O.threshold_hits_chunked(rec, filt, chunk=2048)  # dense f64 matrix + per-hit loop
-    dt = time.perf_counter() - t0
-    return {
-        "value": round(n_records * L / dt / 1e9, 6),
-        "unit": "Gsamples/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"first {n_records} records x {L} samples of the same chunk "
-                  f"({n_records * L:.3g} samples, {dt:.1f} s): baseline mean + per-record scipy "
-                  "savgol_filter + reference per-hit loop",
-        "_hits": hits,
-    }
-
-
-def main() -> None:
-    # stdout carries exactly one JSON line: library banners (gloo, RCCL) are sent to stderr
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    from waveformanalysis_amd import _lib as _wfa_lib
-
-    _wfa_lib.load()  # bind /opt/rocm's HIP + RCCL before torch (which bundles its own copies) is imported
+def parse_args() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -83,26 +56,118 @@ def main() -> None:
     ap.add_argument("--cpu-records", type=int, default=125_000, help="records in the CPU baseline slice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threshold", type=float, default=10.0, help="hit threshold (reference default 10.0)")
-    ap.add_argument("--no-features", action="store_true", help="skip the untimed feature / filter kernels")
-    ap.add_argument("--grouping", action="store_true",
-                    help="also run the event grouping of the (gathered) hit rows on rank 0 (untimed extra)")
-    args = ap.parse_args()
+    ap.add_argument("--no-features", action="store_true", help="skip the untimed feature / filter / end-to-end extras")
+    ap.add_argument("--master-port", type=int, default=int(os.environ.get("WFA_BENCH_PORT", "29613")))
+    return ap.parse_args()
+
+
+def launch_ranks(args: argparse.Namespace) -> int:
+    """`python bench.py --gpus N` without a launcher: start the ranks as a fresh child process tree (this process has not
+    loaded libwfa_hip / torch and never will), relay rank 0's line, return the children's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = next((ln for ln in reversed(proc.stdout.splitlines()) if ln.startswith("{")), None)
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if (line is not None or proc.returncode) else 1
+
+
+def cpu_baseline(records, pool, n_records: int) -> dict:
+    """Time the oracle (port of the reference loops) on the first n_records of the chunk: per-record scipy savgol_filter
+    batches on a thread pool of os.cpu_count() workers (the reference's WavePoolFilteredPlugin default, max_workers=None
+    -> all cores, cpu/records.py:405-430), then the single-threaded dense float64 matrix + per-hit loop of
+    ThresholdHitPlugin (no parallelism there in the reference)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    from oracle import wfa_oracle as O
+    from waveformanalysis_amd import synth
+
+    L = int(records["event_length"][0])
+    rec = records[:n_records].copy()
+    sub = pool[: n_records * L]
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    rec["baseline"] = O.baseline_mean(sub.reshape(-1, L), 0, synth.BASELINE_SAMPLES)
+    filt = np.zeros(len(sub), dtype=np.float32)
+    batch = 1024  # records per task (the reference batches per channel x batch_size)
+    bounds = [(lo, min(lo + batch, n_records)) for lo in range(0, n_records, batch)]
+
+    def work(b):
+        lo, hi = b
+        part = rec[lo:hi].copy()
+        part["wave_offset"] -= lo * L
+        filt[lo * L : hi * L] = O.filter_wave_pool(part, sub[lo * L : hi * L])
+
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, bounds))
+    t_filter = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    hits = O.threshold_hits_chunked(rec, filt, chunk=2048)  # dense f64 matrix + per-hit loop
+    t_hits = time.perf_counter() - t1
+    dt = t_filter + t_hits
+    return {
+        "value": round(n_records * L / dt / 1e9, 6),
+        "unit": "Gsamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n_records} records x {L} samples of the same chunk ({n_records * L:.3g} samples): baseline mean "
+                  f"+ per-record scipy savgol_filter on {cores} threads ({t_filter:.1f} s) + reference dense-matrix / "
+                  f"per-hit loop on 1 thread ({t_hits:.1f} s)",
+        "_hits": hits,
+    }
+
+
+def traffic_entry(kname: str, preset: str, n_records: int, L: int):
+    """HBM bytes per launch of `kname` on exactly this workload, from the PMC capture under profiles/ (or None)."""
+    path = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None, None
+    ent = table.get(f"{kname}|{preset}|{n_records}|{L}")
+    if not isinstance(ent, dict):
+        return None, None
+    return ent.get("bytes"), {k: ent.get(k) for k in ("fetch_bytes", "write_bytes", "commit", "source")}
+
+
+def rank_main(args: argparse.Namespace) -> int:
+    # stdout carries exactly one JSON line: library banners (gloo, RCCL) are sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import numpy as np
+
+    from waveformanalysis_amd import _lib as _wfa_lib
+    from waveformanalysis_amd import synth
+
+    stub = os.environ.get("WFA_BENCH_STUB")  # tests only: a device stand-in, so that the launch / rendezvous / gather /
+    if stub:                                 # exit-status logic of this file can be rehearsed on CPU (tests/bench_stub.py)
+        import importlib
+
+        DeviceSession = importlib.import_module(stub).Session
+    else:
+        _wfa_lib.load()  # bind /opt/rocm's HIP + RCCL before torch (which bundles its own copies) is imported
+        from waveformanalysis_amd.device import DeviceSession
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
-        # torch.distributed is control plane only (rendezvous, barrier, max over ranks, RCCL id
-        # broadcast): gloo, so torch never opens the GPU next to libwfa_hip's own HIP/RCCL runtime.
+        # torch.distributed is control plane only (rendezvous, barrier, max over ranks, RCCL id broadcast): gloo, so
+        # torch never opens the GPU next to libwfa_hip's own HIP/RCCL runtime.
         import torch.distributed as dist_mod
 
         dist = dist_mod
         dist.init_process_group(backend="gloo")
     device_id = 0 if os.environ.get("WFA_BENCH_SHARE_GPU") else local_rank  # rehearsal on a 1-GPU box
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+    n_gpus = world
 
     # ---- synthetic chunk of this rank (channel shard = its own seed) ---------------------------------
     t0 = time.perf_counter()
@@ -114,6 +179,7 @@ def main() -> None:
     sess = DeviceSession(device_id)
     t0 = time.perf_counter()
     sess.upload_pool(pool)
+    h2d_rate = sess.last_h2d_rate()
     rec_in = records.copy()
     rec_in["baseline"] = np.nan  # the fused pass estimates it
     sess.upload_records(rec_in, args.threshold)
@@ -124,7 +190,8 @@ def main() -> None:
         return sess.fused_baseline_filter_hits((0, synth.BASELINE_SAMPLES), 2, 2, download=False)
 
     def step_enqueue() -> None:
-        # the same pass queued without a host round trip: consecutive passes run back to back on the device
+        # the same pass queued without a host round trip (wfa_hits_enqueue, the entry point the chunk-stream plugin
+        # drives): consecutive passes run back to back on the device
         sess.hits_enqueue(_wfa_lib.SRC_SG_FUSED, (0, synth.BASELINE_SAMPLES), 2, 2)
 
     def sync_all() -> None:
@@ -135,7 +202,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     # timed region: HIP events only around the dominant (streaming) kernel -- the roofline figure needs its live
-    # duration; event pairs around the four small follow-up kernels of a pass cost about what the gaps between them do
+    # duration; event pairs around the small follow-up kernels of a pass cost about what the gaps between them do
     sess.profile(2)
     sync_all()
     t0 = time.perf_counter()
@@ -160,18 +227,13 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- event-grouping exchange (RCCL over xGMI), outside the timed region ---------------------------
-    gather_ms = None
-    gather_note = None
-    rows = None
-    total_hits = n_hits
+    # ---- event-grouping exchange (RCCL over xGMI) + grouping on the root, outside the timed region ----------------
+    gather = None
+    gather_ok = True
     if dist is not None:
-        from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
-
-        # The exchange is reported next to the metric, which does not depend on it: it runs on a watchdog thread so that
-        # a transport that never comes up (the 8-GPU node is not available to the build sessions) cannot take the
-        # measured line with it.
         import threading
+
+        from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
 
         box: dict = {}
 
@@ -180,38 +242,44 @@ def main() -> None:
                 uid = [DeviceSession.rccl_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 sess.rccl_init(rank, world, uid[0])
-                sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)  # warm-up (connection setup)
+                sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0, download=False)  # connection setup
                 dist.barrier()
                 t1 = time.perf_counter()
-                counts, got = sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0)
+                counts, _none = sess.rccl_gather_rows(None, n_hits, THRESHOLD_HIT_DTYPE, root=0, download=False)
                 box["ms"] = (time.perf_counter() - t1) * 1e3
                 box["total"] = int(counts.sum())
-                box["rows"] = got
-                if rank == 0:
-                    assert got is not None and len(got) == box["total"]
+                if rank == 0:  # grouping straight from the gathered device buffer
+                    sess.hit_rows_source("gather")
+                    t2 = time.perf_counter()
+                    flat = sess.group_hit_windows_resident(box["total"], 100.0)
+                    box["group_ms"] = (time.perf_counter() - t2) * 1e3
+                    box["events"] = int(len(flat["event_start"]) - 1)
+                    sess.hit_rows_source("hits")
+                box["ok"] = True
             except Exception as exc:  # noqa: BLE001
-                box["note"] = f"RCCL gather not run: {exc}"
+                box["note"] = f"{type(exc).__name__}: {exc}"
 
         th = threading.Thread(target=exchange, daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("WFA_BENCH_GATHER_TIMEOUT_S", "120")))
-        if th.is_alive():
-            gather_note = "RCCL gather did not finish within the watchdog time; metric line unaffected"
-            hung = True
-        else:
-            hung = False
-            gather_ms, gather_note = box.get("ms"), box.get("note")
-            rows = box.get("rows")
-            total_hits = box.get("total", n_hits)
-    else:
-        hung = False
+        hung = th.is_alive()
+        gather_ok = bool(box.get("ok")) and not hung
+        gather = {"ok": gather_ok, "hung": hung, "ms": box.get("ms"), "hits_total": box.get("total"),
+                  "group_hit_windows_ms": box.get("group_ms"), "events": box.get("events"), "note": box.get("note"),
+                  "time_window_ns": 100.0, "rows": "device-resident on rank 0 (no host copy)"}
+        if not hung:
+            # every rank learns whether any rank failed, so that all exit with the same status
+            import torch
 
-    # ---- the other per-record kernels of the path, timed once each (not part of the metric) ----------
-    extra_ms = {}
-    if rank == 0 and not args.no_features and not hung:
+            flag = torch.tensor([0 if gather_ok else 1], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            gather_ok = gather_ok and int(flag.item()) == 0
+            gather["ok"] = gather_ok
+
+    # ---- the other kernels of the path on the same chunk, timed once each (not part of the metric) ----------------
+    extra_ms, c3, e2e = {}, None, None
+    if rank == 0 and not args.no_features and gather_ok:
         from waveformanalysis_amd import _lib as L_
-
-        from waveformanalysis_amd.event_grouping import group_hit_windows_flat
         from waveformanalysis_amd.hit_merge import compute_cluster_rows, compute_merged_rows
 
         hit_rows = sess._fill_hits(n_hits)
@@ -222,26 +290,45 @@ def main() -> None:
             sess.savgol(download=False)
             # find_peaks hit detector on the filtered pool that savgol just left resident (reference defaults)
             n_peaks = len(sess.find_peaks(L_.SRC_F32))
-            # hit-table stages on this rank's threshold hits: merge (gap 20 ns), then event grouping (100 ns)
+            # hit-table stages on this rank's threshold hits, straight from the rows the pass left on the device: merge
+            # (gap 20 ns), then event grouping (100 ns)
+            sess.hit_rows_source("hits")
+            _order, offset = sess.hit_merge_clusters_resident(n_hits, 20.0, 10000.0)
+            flat = sess.group_hit_windows_resident(n_hits, 100.0)
             clusters = compute_cluster_rows(sess, hit_rows, 20.0, 10000.0, None, "bench")
             merged = compute_merged_rows(sess, hit_rows, clusters, None, "bench")
-            flat = group_hit_windows_flat(hit_rows, 100.0, session=sess)
             # records builder: global order of the records (already sorted: the sort still runs all passes)
             sess.records_sort_order(records["timestamp"], records["pid"], records["board"], records["channel"])
-        extra_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in sess.profile_report().items()}
-        extra_ms["_counts"] = {"peaks": int(n_peaks), "merged_hits": int(len(merged)),
+        rep = sess.profile_report()
+        extra_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in rep.items()}
+        extra_ms["_counts"] = {"peaks": int(n_peaks), "merged_hits": int(len(merged)), "clusters": int(len(offset) - 1),
                                "events": int(len(flat["event_start"]) - 1)}
         sess.profile(False)
+        # BASELINE config 3: records -> hits -> BasicFeatures(area, width) on the 1e9-sample chunk
+        pass_ms = sum(v[0] / max(v[1], 1) for v in prof_all.values())
+        c3 = {"hits_pass_ms": round(pass_ms, 4), "k_basic_features_ms": extra_ms.get("k_basic_features"),
+              "k_width_integral_ms": extra_ms.get("k_width_integral")}
+        if c3["k_basic_features_ms"] is not None and c3["k_width_integral_ms"] is not None:
+            c3["total_ms"] = round(pass_ms + c3["k_basic_features_ms"] + c3["k_width_integral_ms"], 4)
+            c3["Gsamples_per_s"] = round(n_samples / c3["total_ms"] / 1e6, 1)
+        # end to end through the plugin boundary: host arrays in, structured rows out (H2D + kernels + D2H)
+        try:
+            from waveformanalysis_amd.plugin_api import SimpleContext
+            from waveformanalysis_amd.plugins import HipThresholdHitPlugin
 
-    grouping = None
-    if rank == 0 and args.grouping and not hung:
-        from waveformanalysis_amd.event_grouping import group_hit_windows_flat
-
-        all_rows = rows if (dist is not None and gather_ms is not None) else sess._fill_hits(n_hits)
-        t0 = time.perf_counter()
-        flat = group_hit_windows_flat(all_rows, 100.0)
-        grouping = {"hits": int(len(all_rows)), "events": int(len(flat["event_start"]) - 1),
-                    "host_ms": round((time.perf_counter() - t0) * 1e3, 1), "time_window_ns": 100.0}
+            ctx = SimpleContext({"wave_source": "records", "use_filtered": True, "fuse_filter": True,
+                                 "fuse_baseline": (0, synth.BASELINE_SAMPLES), "threshold": args.threshold},
+                                {"records": rec_in, "wave_pool": pool})
+            ctx.wfa_device_pool = None
+            plugin = HipThresholdHitPlugin()
+            t1 = time.perf_counter()
+            rows = plugin.compute(ctx, "bench")
+            dt = time.perf_counter() - t1
+            e2e = {"value": round(n_samples / dt / 1e9, 3), "unit": "Gsamples/s", "seconds": round(dt, 3),
+                   "rows": int(len(rows)), "what": "HipThresholdHitPlugin.compute: H2D of pool + records (pinned staging "
+                   "ring), fused pass, D2H of the hit rows"}
+        except Exception as exc:  # noqa: BLE001
+            e2e = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -251,13 +338,7 @@ def main() -> None:
         k_avg_s = (k_ms / k_n) * 1e-3 if k_n else float("nan")
         algo_bytes = 2 * n_samples + 29 * len(records) + 60 * n_hits
         achieved = algo_bytes / k_avg_s / 1e9 if k_n else float("nan")
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(kname)
-            except Exception:
-                traffic = None
+        traffic, traffic_src = traffic_entry(kname, args.preset, len(records), L)
         out = {
             "metric": "Gsamples/s baseline+filter+hitfind",
             "value": round(value, 3),
@@ -287,31 +368,36 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": kname,
                 "kernel_avg_ms": round(k_avg_s * 1e3, 4),
                 "algorithmic_bytes": algo_bytes,
+                "frac_pass": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "kernels_ms": {**{k: round(v[0] / max(v[1], 1), 4) for k, v in prof_all.items()},
                            **{k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}},
             "kernels_ms_note": f"{kname}: HIP events inside the timed region; the others: 3 extra passes after it",
             "other_kernels_ms": extra_ms,
-            "setup": {"generate_s": round(gen_s, 2), "h2d_s": round(h2d_s, 3),
-                      "h2d_GBps": round((2 * n_samples) / h2d_s / 1e9, 2)},
+            "setup": {"generate_s": round(gen_s, 2), "h2d_s": round(h2d_s, 3), "h2d_GBps": round(h2d_rate, 2),
+                      "h2d_note": "wave_pool through two pinned 32-MiB staging buffers"},
         }
-        if gather_ms is not None:
-            out["gather_ms"] = round(gather_ms, 3)
-            out["config"]["hits_total"] = total_hits
-        if gather_note:
-            out["gather_note"] = gather_note
-        if grouping:
-            out["event_grouping"] = grouping
+        if c3:
+            out["config3"] = c3
+        if e2e:
+            out["end_to_end"] = e2e
+        if gather is not None:
+            out["gather_ok"] = gather_ok
+            out["gather"] = gather
+            if gather.get("ms") is not None:
+                out["gather_ms"] = round(gather["ms"], 3)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a 1-GPU-run figure (rank 0, N = 1)
             n_cpu = min(args.cpu_records, len(records))
             cb = cpu_baseline(records, pool, n_cpu)
             cpu_hits = cb.pop("_hits")
             out["cpu_baseline"] = cb
             # parity on the slice: rows of the first n_cpu records, integer fields bit-exact
-            gpu_hits = sess._fill_hits(n_hits)
+            n_chk = step()
+            gpu_hits = sess._fill_hits(n_chk)
             sel = gpu_hits[gpu_hits["record_id"] < n_cpu]
             int_ok = len(sel) == len(cpu_hits) and all(
                 np.array_equal(sel[f], cpu_hits[f]) for f in sel.dtype.names if sel.dtype[f].kind in "iu")
@@ -321,12 +407,25 @@ def main() -> None:
                              "int_fields_bit_exact": bool(int_ok), "max_rel_err_float_fields": flt}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if hung:
-        os._exit(0)  # a stuck transport thread would block the teardown; the line is out
+    if not gather_ok:
+        # a failed or hung exchange is a finding: the line is out, every rank leaves with the same non-zero status
+        # (no teardown: a stuck transport thread would block it)
+        os._exit(EXIT_GATHER_FAILED)
     sess.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")) and int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: the launcher decides",
+              file=sys.stderr)
+    return rank_main(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -63,6 +63,19 @@ int wfa_last_error(char* buf, size_t buf_len);
 int wfa_ctx_create(int device_id, wfa_ctx** out);
 void wfa_ctx_destroy(wfa_ctx* ctx);
 int wfa_sync(wfa_ctx* ctx);
+/* Choice between code paths that produce identical results (no counterpart in the reference: its plugins have one
+ * code path).  For tests, which compare the paths with each other, and for measurement; a caller never needs it.
+ * Names: "no_fast" (literal float64 hit kernel), "no_span" (per-record mask kernel), "no_pad" (no padded shadow
+ * layout), "no_runs32" (bitmap route instead of the run-event kernel), "no_speculate" (exact row launches). */
+int wfa_set_option(wfa_ctx* ctx, const char* name, int value);
+/* GB/s of the last pool upload through the pinned staging ring (uploads of >= 4 MiB are copied chunk by chunk into two
+ * pinned 32-MiB buffers while the previous chunk is on the wire; reference: the plugins hold host arrays only). */
+int wfa_last_h2d_rate(wfa_ctx* ctx, double* gb_per_s);
+/* Source of the device-resident THRESHOLD_HIT_DTYPE rows that wfa_hit_merge_count / wfa_group_hit_windows_count read
+ * when ALL their column pointers are NULL: 1 = rows of the last hit pass (default), 2 = rows the last
+ * wfa_rccl_gather_rows left on the root.  Replaces the host columns hit_merge.py:115-181 / event_grouping.py:418-471
+ * take from the structured array: no upload, no download between the stages. */
+int wfa_hit_rows_source(wfa_ctx* ctx, int which);
 
 /* ---- resident inputs -------------------------------------------------------------------- */
 

@@ -139,3 +139,40 @@ def test_hit_table_edge_cases(sess):
     no_dt = np.zeros(3, dtype=[(n, THRESHOLD_HIT_DTYPE.fields[n][0]) for n in THRESHOLD_HIT_DTYPE.names if n != "dt"])
     with pytest.raises(ValueError, match="missing required field 'dt'"):
         compute_cluster_rows(sess, no_dt, 10.0, 100.0, None, "hit_merge_clusters")
+
+
+def test_resident_rows_feed_merge_and_grouping_without_host_columns():
+    """wfa_hit_merge_count / wfa_group_hit_windows_count with all column pointers NULL read the device-resident rows of the
+    last hit pass (and, on a 1-rank communicator, of the last RCCL gather): same tables as with uploaded columns."""
+    from waveformanalysis_amd import _lib, synth
+    from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
+
+    rec, pool = synth.make_run(4000, "v1725", cfg=91)
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.upload_records(rec, 10.0)
+        sess.set_sg_plan(11, 2)
+        rows = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
+        n = len(rows)
+        assert n > 3000
+        want_g = sess.group_hit_windows(rows["timestamp"], rows["position"], rows["edge_start"], rows["edge_end"], rows["dt"],
+                                        rows["board"], rows["channel"], rows["record_id"], 100.0)
+        want_m = sess.hit_merge_clusters(rows["timestamp"], rows["position"], rows["edge_start"], rows["edge_end"], rows["dt"],
+                                         rows["board"], rows["channel"], 20.0, 10000.0)
+        sess.hit_rows_source("hits")
+        got_g = sess.group_hit_windows_resident(n, 100.0)
+        got_m = sess.hit_merge_clusters_resident(n, 20.0, 10000.0)
+        for k in want_g:
+            np.testing.assert_array_equal(got_g[k], want_g[k], err_msg=k)
+        np.testing.assert_array_equal(got_m[0], want_m[0])
+        np.testing.assert_array_equal(got_m[1], want_m[1])
+        # through a gather (1 rank): rows stay on the device, nothing is downloaded
+        sess.rccl_init(0, 1, DeviceSession.rccl_unique_id())
+        counts, none = sess.rccl_gather_rows(None, n, THRESHOLD_HIT_DTYPE, root=0, download=False)
+        assert none is None and int(counts.sum()) == n
+        sess.hit_rows_source("gather")
+        got_g2 = sess.group_hit_windows_resident(n, 100.0)
+        for k in want_g:
+            np.testing.assert_array_equal(got_g2[k], want_g[k], err_msg=f"gather {k}")
+        with pytest.raises(ValueError, match="resident hit table has"):
+            sess.group_hit_windows_resident(n + 1, 100.0)

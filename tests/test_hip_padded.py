@@ -1,7 +1,7 @@
 """Uniform records whose length is not a multiple of 16 samples (VX2730: 1500) take the span16 kernels on a padded
 shadow layout built on the device.  Lengths around the supported boundary (L % 16 >= half window), both polarities,
 fused and given baselines, and odd pool offsets, against the oracle and against the per-record kernels
-(WFA_DISABLE_PAD) -- integer fields exact, floats within the threshold-hit tolerance."""
+(option no_pad) -- integer fields exact, floats within the threshold-hit tolerance."""
 
 import os
 
@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 FLOAT_RTOL = 1e-6
 
 
-def _run(rec, pool, fused_baseline, **env):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+def _run(rec, pool, fused_baseline, **options):
+    if True:
         with DeviceSession(0) as sess:
+            for name, value in options.items():
+                sess.set_option(name, value)
             sess.upload_pool(pool)
             sess.upload_records(rec, 10.0)
             sess.set_sg_plan(11, 2)
@@ -32,9 +32,6 @@ def _run(rec, pool, fused_baseline, **env):
                 rows = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
             again = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)      # shadow re-used, baselines now on the device
             return rows, again, set(sess.profile_report())
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
 
 @pytest.mark.parametrize("L", [1500, 1000, 37, 44, 47, 36, 100])
@@ -72,7 +69,7 @@ def test_padded_layout_matches_oracle(L, polarity):
         assert any("span16" in k or "runs32" in k for k in kernels) == expect_pad, kernels  # a uniform-record kernel
         G.assert_struct_equal(rows, want, float_rtol=FLOAT_RTOL, what=f"L={L} fused_baseline={fused_baseline}")
         G.assert_struct_equal(again, want, float_rtol=FLOAT_RTOL, what="second pass")
-        plain, _a, kernels2 = _run(rec_in, pool, fused_baseline, WFA_DISABLE_PAD="1")
+        plain, _a, kernels2 = _run(rec_in, pool, fused_baseline, no_pad=True)
         assert not any("k_pad_rows" in k for k in kernels2)
         assert plain.tobytes() == rows.tobytes()                      # the per-record kernels agree byte for byte
 
@@ -80,7 +77,7 @@ def test_padded_layout_matches_oracle(L, polarity):
 @pytest.mark.parametrize("L", [1500, 1000, 100, 37, 47])
 def test_padded_materialised_filter_bit_exact(L):
     """wave_pool_filtered through the span kernel on the shadow layout == scipy's float32 output == the per-record
-    kernel (WFA_DISABLE_PAD), for every window the integer plan covers and for a low pedestal (literal branch)."""
+    kernel (option no_pad), for every window the integer plan covers and for a low pedestal (literal branch)."""
     rec, pool = synth.make_run(300 if L > 200 else 2000, "vx2730", cfg=70 + L % 50, L=L)
     rng = np.random.default_rng(L + 1)
     w = pool.reshape(len(rec), L).astype(np.int32)
@@ -93,19 +90,14 @@ def test_padded_materialised_filter_bit_exact(L):
     for W, P in ((11, 2), (7, 3), (15, 4), (5, 2)):
         want = O.filter_wave_pool(rec, pool, sg_window_size=W, sg_poly_order=P)
         outs = {}
-        for env in ({}, {"WFA_DISABLE_PAD": "1"}):
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
-            try:
-                with DeviceSession(0) as sess:
-                    sess.upload_pool(pool)
-                    sess.upload_records(rec, 10.0)
-                    plan = sess.set_sg_plan(W, P)
-                    sess.profile(True)
-                    outs[bool(env)] = (sess.savgol(), set(sess.profile_report()))
-            finally:
-                for k, v in old.items():
-                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        for no_pad in (False, True):
+            with DeviceSession(0) as sess:
+                sess.set_option("no_pad", no_pad)
+                sess.upload_pool(pool)
+                sess.upload_records(rec, 10.0)
+                plan = sess.set_sg_plan(W, P)
+                sess.profile(True)
+                outs[no_pad] = (sess.savgol(), set(sess.profile_report()))
         got, kernels = outs[False]
         # windows without an integer plan take the literal float64 kernel in every layout
         assert any("k_savgol_span<padded>" in k for k in kernels) == bool(plan.int_ok), (W, P, kernels)

@@ -12,12 +12,13 @@ for d in ${PMC_DBG:-0 15}; do
   done
 done
 python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, os
+KSEL = os.environ.get("PMC_KERNEL", "runs32")
 for d in sorted(set(f.split("_")[2] for f in glob.glob("gpurun_out/pq_*_*.csv"))):
     agg = collections.defaultdict(float); cnt = collections.defaultdict(int)
     for f in glob.glob(f"gpurun_out/pq_{d}_*.csv"):
         for row in csv.DictReader(open(f)):
-            if "runs32" in row["Kernel_Name"]:
+            if ("runs32" in row["Kernel_Name"]) == (KSEL == "runs32") and (KSEL in row["Kernel_Name"]):
                 agg[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
-    print("DBG", d, {c: round(agg[c] / cnt[c] / 488281.25, 1) for c in sorted(agg)}, "(per 2048-sample tile)")
+    print("DBG", d, {c: round(agg[c] / cnt[c] / float(os.environ.get("PMC_DIV", "488281.25")), 1) for c in sorted(agg)}, "(per unit)")
 PY

@@ -5,6 +5,8 @@
 #include <new>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 #include "wfa_common.hpp"
 #include "wfa_kernels.hpp"
@@ -53,9 +55,54 @@ static int use_device(wfa_ctx* c) {
     return WFA_OK;
 }
 
+constexpr size_t kStageBytes = 32u << 20;   // per staging buffer
+constexpr size_t kStageMin = 4u << 20;      // smaller copies go straight through hipMemcpyAsync
+constexpr int kStageThreads = 4;
+
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    if (bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
+    std::thread th[kStageThreads - 1];
+    const size_t part = (bytes / kStageThreads + 4095) & ~(size_t)4095;
+    for (int t = 1; t < kStageThreads; ++t) {
+        const size_t o = (size_t)t * part;
+        if (o >= bytes) break;
+        const size_t n = o + part < bytes ? part : bytes - o;
+        th[t - 1] = std::thread([=] { memcpy((char*)dst + o, (const char*)src + o, n); });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (auto& x : th) if (x.joinable()) x.join();
+}
+
+// host -> device through the context's pinned double buffer (see wfa_ctx::stage); returns when the last chunk is queued
+static int h2d_staged(wfa_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c->stage[0]) {
+        for (int b = 0; b < 2; ++b) {
+            WFA_HIP_CHECK(hipHostMalloc(&c->stage[b], kStageBytes, hipHostMallocDefault));
+            WFA_HIP_CHECK(hipEventCreateWithFlags(&c->stage_ev[b], hipEventDisableTiming));
+        }
+        c->stage_bytes = kStageBytes;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    bool used[2] = {false, false};
+    int b = 0;
+    for (size_t off = 0; off < bytes; off += kStageBytes, b ^= 1) {
+        const size_t n = bytes - off < kStageBytes ? bytes - off : kStageBytes;
+        if (used[b]) WFA_HIP_CHECK(hipEventSynchronize(c->stage_ev[b]));  // the copy out of this buffer has finished
+        parallel_memcpy(c->stage[b], (const char*)src + off, n);
+        WFA_HIP_CHECK(hipMemcpyAsync((char*)dst + off, c->stage[b], n, hipMemcpyHostToDevice, c->stream));
+        WFA_HIP_CHECK(hipEventRecord(c->stage_ev[b], c->stream));
+        used[b] = true;
+    }
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));  // the staging buffers are free again for the next call
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (s > 0) c->last_h2d_GBps = (double)bytes / s / 1e9;
+    return WFA_OK;
+}
+
 static int h2d(wfa_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     int rc = b.ensure(bytes);
     if (rc) return rc;
+    if (bytes >= kStageMin) return h2d_staged(c, b.ptr, src, bytes);
     if (bytes) WFA_HIP_CHECK(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, c->stream));
     return WFA_OK;
 }
@@ -100,7 +147,6 @@ static SgParams sg_params(wfa_ctx* c) {
     // |y| < 2^17 for uint16 samples (sum|c| < 2): float32 ulp <= 2^-7
     s.margin = (int32_t)((c->sg.den + 127) / 128 + 2);
     s.margin_edge = (int32_t)((c->sg.den_edge + 127) / 128 + 2);
-    s.mfma_tab = c->sg.mfma_ok ? c->sg.mfma.as<int8_t>() : nullptr;
     return s;
 }
 
@@ -146,13 +192,13 @@ static int ensure_shadow(wfa_ctx* c) {
 static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t bl_end, int32_t le, int32_t re,
                            int32_t max_len, int64_t* n_hits, bool enqueue_only, bool* done) {
     *done = false;
-    if (c->no_runs32 || getenv("WFA_DISABLE_RUNS32")) return WFA_OK;
+    if (c->no_runs32 || c->opt.no_runs32) return WFA_OK;
     const SgParams sp0 = sg_params(c);
     SpanParams sp{};
     bool padded = false;
     if (c->span_ok && c->span_L % 32 == 0) {
         sp.off0 = c->span_off0; sp.L = c->span_L; sp.S = c->span_L; sp.positive = c->span_positive;
-    } else if (c->pad_ok && c->pad_S % 32 == 0 && !getenv("WFA_DISABLE_PAD")) {
+    } else if (c->pad_ok && c->pad_S % 32 == 0 && !c->opt.no_pad) {
         padded = true;
         sp.off0 = 0; sp.L = c->pad_L; sp.S = c->pad_S; sp.positive = c->pad_positive;
     } else {
@@ -189,7 +235,7 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         // speculative tail (see run_hits): row buffers sized from the previous pass on this context
         const int64_t held = (int64_t)std::min(c->hit_out.cap / 60, c->hit_desc.cap / sizeof(int4));
         const int64_t bound = c->last_hits + c->last_hits / 8 + 4096;
-        const bool spec = c->last_hits >= 0 && held >= bound && !getenv("WFA_NO_SPECULATE") && attempt == 0;
+        const bool spec = c->last_hits >= 0 && held >= bound && !c->opt.no_speculate && attempt == 0;
         int64_t ev_want = spec ? 2 * bound : std::max<int64_t>(2 * bound, R * 8 + 4096);
         if ((int64_t)(c->run_ev.cap / sizeof(uint32_t)) < ev_want)
             if ((rc = c->run_ev.ensure((size_t)ev_want * sizeof(uint32_t)))) return rc;
@@ -208,7 +254,9 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         // sg_plan.py: guard = 8 eps den^2 2^24 + 1 with eps = bound on |scipy's float64 chain - exact rational|; here in
         // numerator units with a factor 4 of head room (and never below 1e-6)
         ra.delta = std::max(4.0 * (double)sp0.guard / (8.0 * (double)sp0.den * 16777216.0), 1e-6);
-        ra.dbg = getenv("WFA_RUNS_DBG") ? atoi(getenv("WFA_RUNS_DBG")) : 0;
+#ifdef WFA_MEASURE
+        ra.dbg = getenv("WFA_RUNS_DBG") ? atoi(getenv("WFA_RUNS_DBG")) : 0;  // results are NOT valid with it set
+#endif
         ra.W = sp0.W; ra.L = sp.L; ra.S = sp.S; ra.positive = sp.positive; ra.rs = sp.rs;
         ra.off0 = sp.off0; ra.n_spans = ns;
         ra.ev = rn.ev; ra.ev_cap = rn.ev_cap; ra.cursor = rn.cursor; ra.span_off = rn.span_off; ra.span_cnt = rn.span_cnt;
@@ -345,7 +393,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
     const PoolView pv0 = pool_view(c);
     const RecView rv0 = rec_view(c);
     const SgParams sp0 = sg_params(c);
-    if (source == WFA_SRC_SG_FUSED && sg_mask_supported(sp0) && !getenv("WFA_DISABLE_FAST")) {
+    if (source == WFA_SRC_SG_FUSED && sg_mask_supported(sp0) && !c->opt.no_fast) {
         {
             bool done = false;
             if ((rc = run_hits_runs32(c, fused_bl, bl_start, bl_end, le, re, max_len, n_hits, enqueue_only, &done))) return rc;
@@ -365,15 +413,15 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         // views the kernels of this pass read: the uploaded layout, or the padded shadow of it
         PoolView pvf = pv0;
         RecView rvf = rv0;
-        const bool padded = c->pad_ok && sg_mask_span16_padded_supported(sp0, c->pad_L) && !getenv("WFA_DISABLE_PAD") &&
-                            !getenv("WFA_DISABLE_SPAN") && !getenv("WFA_DISABLE_SPAN16");
+        const bool padded = c->pad_ok && sg_mask_span16_padded_supported(sp0, c->pad_L) && !c->opt.no_pad &&
+                            !c->opt.no_span;
         if (padded) {
             if ((rc = ensure_shadow(c))) return rc;
             pvf.u16 = c->shadow_pool.as<uint16_t>();
             pvf.n = c->R * (int64_t)c->pad_S;
             rvf.off = c->shadow_off.as<int64_t>();
         }
-        if (padded || (c->span_ok && c->span_L >= sp0.W && !getenv("WFA_DISABLE_SPAN"))) {
+        if (padded || (c->span_ok && c->span_L >= sp0.W && !c->opt.no_span)) {
             SpanParams sp{};
             sp.off0 = c->span_off0; sp.L = c->span_L; sp.positive = c->span_positive;
             if (padded) { sp.off0 = 0; sp.L = c->pad_L; sp.S = c->pad_S; sp.positive = c->pad_positive; }
@@ -381,18 +429,14 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             sp.rs = 64;
             sp.n_spans = (R + sp.rs - 1) / sp.rs;
             sp.bm_off0 = 0;
-            sp.dbg = getenv("WFA_SPAN_DBG") ? atoi(getenv("WFA_SPAN_DBG")) : 0;
             sp.bm_stride = ((int64_t)span_L + 7 + 63) / 64 * 8 + 8;
             LaunchTimer t(c, true);
-            if (!padded && sg_mask_mfma_supported(sp0, span_L) && getenv("WFA_ENABLE_MFMA")) {  // experiment, see DESIGN.md
-                WFA_HIP_CHECK(launch_sg_mask_span_mfma(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
-                if ((rc = t.end(fused_bl ? "k_sg_mask_span_mfma<baseline>" : "k_sg_mask_span_mfma"))) return rc;
-            } else if (padded || (sg_mask_span16_supported(sp0, span_L) && !getenv("WFA_DISABLE_SPAN16"))) {
+            if (padded || (sg_mask_span16_supported(sp0, span_L))) {
                 WFA_HIP_CHECK(launch_sg_mask_span16(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
                 if ((rc = t.end(fused_bl ? "k_sg_mask_span16<baseline>" : "k_sg_mask_span16"))) return rc;
             } else {
-                WFA_HIP_CHECK(launch_sg_mask_span(c->stream, fused_bl, pvf, rvf, sp0, mp, sp));
-                if ((rc = t.end(fused_bl ? "k_sg_mask_span<baseline>" : "k_sg_mask_span"))) return rc;
+                WFA_HIP_CHECK(launch_sg_mask(c->stream, fused_bl, c->max_len, pvf, rvf, sp0, mp));
+                if ((rc = t.end(fused_bl ? "k_sg_mask<baseline>" : "k_sg_mask"))) return rc;
             }
         } else {
             LaunchTimer t(c, true);
@@ -409,7 +453,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         const int64_t* d_total = c->scan_blocks.as<int64_t>() + nb;
         RowParams rp{le, re, max_len, sp0.W / 2};
         if (padded) { rp.uni_L = c->pad_L; rp.uni_S = c->pad_S; rp.uni_positive = c->pad_positive ? 1 : 0; rp.uni_off0 = 0; }
-        else if (c->span_ok && !getenv("WFA_ROWS_NO_UNIFORM")) { rp.uni_L = c->span_L; rp.uni_positive = c->span_positive ? 1 : 0; rp.uni_off0 = c->span_off0; }
+        else if (c->span_ok) { rp.uni_L = c->span_L; rp.uni_positive = c->span_positive ? 1 : 0; rp.uni_off0 = c->span_off0; }
         {
             // mask bytes of one block's records (+16 for the aligned start), rounded up to 1 KiB
             const int64_t per_rec = ((int64_t)c->max_len + 7 + 63) / 64 * 8 + 8;
@@ -422,7 +466,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         // finds more is redone the exact way below.
         const int64_t held = (int64_t)std::min(c->hit_out.cap / 60, c->hit_desc.cap / sizeof(int4));
         const int64_t bound = c->last_hits + c->last_hits / 8 + 4096;
-        if (c->last_hits >= 0 && held >= bound && !getenv("WFA_NO_SPECULATE")) {
+        if (c->last_hits >= 0 && held >= bound && !c->opt.no_speculate) {
             rp.cap = bound;
             rp.n_dev = d_total;
             {
@@ -498,7 +542,7 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
     hp.bl_start = bl_start; hp.bl_end = bl_end;
     hp.bm_words = (c->max_len + 7 + 63) / 64 + 9;  // bits are indexed from the 16-byte aligned base
     hp.chunk_rows = 256;
-    hp.use_fast = getenv("WFA_DISABLE_FAST") ? 0 : 1;
+    hp.use_fast = c->opt.no_fast ? 0 : 1;
     const int64_t waves = hits_waves(R);
     int64_t want_rows = waves * hp.chunk_rows + c->pool_n / 256 + 4096;
     if (c->hit_tmp_rows < want_rows) {
@@ -616,14 +660,18 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
                       &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
-                        &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.mfma, &c->sg.tab,
+                        &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows,
-                      &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
+                      &c->gathered, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
                       &c->shadow_pool, &c->shadow_off};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ht) b.release();
     if (c->h_total) (void)hipHostFree(c->h_total);
+    for (int b = 0; b < 2; ++b) {
+        if (c->stage[b]) (void)hipHostFree(c->stage[b]);
+        if (c->stage_ev[b]) (void)hipEventDestroy(c->stage_ev[b]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     (void)profile_flush(c);
@@ -631,6 +679,25 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     c->prof_free.clear();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int wfa_set_option(wfa_ctx* c, const char* name, int value) {
+    if (!c || !name) return fail(WFA_E_INVALID, "null argument");
+    const std::string n(name);
+    const bool v = value != 0;
+    if (n == "no_fast") c->opt.no_fast = v;
+    else if (n == "no_span") c->opt.no_span = v;
+    else if (n == "no_pad") c->opt.no_pad = v;
+    else if (n == "no_runs32") c->opt.no_runs32 = v;
+    else if (n == "no_speculate") c->opt.no_speculate = v;
+    else return fail(WFA_E_INVALID, "unknown option '%s'", name);
+    return WFA_OK;
+}
+
+int wfa_last_h2d_rate(wfa_ctx* c, double* gb_per_s) {
+    if (!c || !gb_per_s) return fail(WFA_E_INVALID, "null argument");
+    *gb_per_s = c->last_h2d_GBps;
+    return WFA_OK;
 }
 
 int wfa_sync(wfa_ctx* c) {
@@ -779,37 +846,6 @@ int wfa_set_sg_plan(wfa_ctx* c, int window, int polyorder, const double* tab, co
     } else {
         if ((rc = s.itab.ensure(isz))) return rc;
     }
-    // band matrices of the matrix-core mask kernel, in MFMA A-operand layout (16 x 64 int8):
-    // [polarity 0 (+n) / 1 (-n)][shift prev, own, next][part P (low bytes), Q (high bytes)][lane][16]
-    // lane = 16 g' + r holds A[row r][k = 16 g' + j]; row r = 4 g + i (k-quarter g, output i = 0..3)
-    s.mfma_ok = false;
-    if (int_ok && window >= 5 && window <= 15) {
-        bool fits = true;
-        for (int k = 0; k < window; ++k) fits = fits && itab[k] >= -127 && itab[k] <= 127;
-        if (fits) {
-            std::vector<int8_t> at((size_t)2 * 6 * 64 * 16, 0);
-            const int Hh = window / 2;
-            for (int pol = 0; pol < 2; ++pol)
-                for (int shift = 0; shift < 3; ++shift)
-                    for (int part = 0; part < 2; ++part)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 16; ++j) {
-                                const int row = lane & 15, kq = lane >> 4;
-                                const int g = row >> 2, out = row & 3;
-                                const int sample = j >> 1, byte = j & 1;
-                                int v = 0;
-                                if (kq == g && byte == part) {
-                                    const int tap = sample + 8 * (shift - 1) - out + Hh;
-                                    if (tap >= 0 && tap < window) v = pol ? -itab[tap] : itab[tap];
-                                }
-                                const size_t m = (size_t)((pol * 3 + shift) * 2 + part);
-                                at[(m * 64 + lane) * 16 + j] = (int8_t)v;
-                            }
-            if ((rc = h2d(c, s.mfma, at.data(), at.size()))) return rc;
-            WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
-            s.mfma_ok = true;
-        }
-    }
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->have_sg = true;
     return WFA_OK;
@@ -868,8 +904,8 @@ int wfa_savgol(wfa_ctx* c, float* out) {
     if (c->R > 0) {
         PoolView pv = pool_view(c);
         const SgParams sp0 = sg_params(c);
-        const bool padded = c->pad_ok && c->pad_L >= sp0.W && sg_mask_supported(sp0) && !getenv("WFA_DISABLE_FAST") &&
-                            !getenv("WFA_DISABLE_PAD");
+        const bool padded = c->pad_ok && c->pad_L >= sp0.W && sg_mask_supported(sp0) && !c->opt.no_fast &&
+                            !c->opt.no_pad;
         if (padded && (rc = ensure_shadow(c))) return rc;
         LaunchTimer t(c);
         if (padded) {  // uniform records, L % 16 != 0: span kernel reading the padded shadow, writing the packed pool
@@ -882,7 +918,7 @@ int wfa_savgol(wfa_ctx* c, float* out) {
             WFA_HIP_CHECK(launch_savgol_span(c->stream, pv, rec_view(c), sp0, sp, c->pool_f32.as<float>()));
             if ((rc = t.end("k_savgol_span<padded>"))) return rc;
         } else if (c->span_ok && c->span_L >= 16 && c->span_L >= sp0.W && sg_mask_supported(sp0) &&
-            !getenv("WFA_DISABLE_FAST")) {
+            !c->opt.no_fast) {
             SpanParams sp{};
             sp.off0 = c->span_off0; sp.L = c->span_L; sp.positive = 0;
             sp.rs = 64;

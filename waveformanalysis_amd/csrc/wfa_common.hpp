@@ -60,8 +60,6 @@ struct SgPlanDev {
     DevBuf tab;   // double
     DevBuf itab;  // int32
     DevBuf sym;   // uint8
-    DevBuf mfma;  // int8 band matrices (see k_sg_mask_span_mfma)
-    bool mfma_ok = false;
     std::vector<uint8_t> sym_host;
 };
 
@@ -107,6 +105,22 @@ struct wfa_ctx {
     wfa::DevBuf hit_desc;       // int4 (record, start, end, k) per hit
     // streaming pass on uniform records (k_sg_runs32): event buffer, per-span tables, control words
     wfa::DevBuf run_ev, run_span_off, run_span_cnt, run_span_row0, run_scan_blocks, run_ctrl;
+    // host -> device staging: two pinned buffers; a chunk is copied in (a few host threads) while the previous one is on
+    // the wire.  Pageable hipMemcpyAsync of a whole pool depends on the driver's own staging (5 GB/s on one box, 0.03
+    // GB/s on another)
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    double last_h2d_GBps = 0.0;  // rate of the last staged upload (wfa_last_h2d_rate)
+
+    // wfa_set_option: choice between code paths that give identical results (tests compare them; a caller never needs to)
+    struct {
+        bool no_fast = false;      // literal float64 k_hits instead of the integer kernels
+        bool no_span = false;      // per-record mask kernel instead of the uniform-record kernels
+        bool no_pad = false;       // no padded shadow layout
+        bool no_runs32 = false;    // bitmap route (k_sg_mask_span16 + scan + k_hit_runs) instead of k_sg_runs32
+        bool no_speculate = false; // exact row launches (host round trip for the hit count)
+    } opt;
     wfa::RunsCold* h_cold = nullptr;   // pinned staging (lives behind h_total)
     wfa::RunsCold run_cold_host{};     // what the device copy holds
     bool run_cold_valid = false;
@@ -123,6 +137,9 @@ struct wfa_ctx {
     wfa::DevBuf wh_pos, wh_row, wh_valid;  // per-hit inputs of k_waveform_width
     // hit-table stages (wfa_hits.hip): scratch slots and the state of the last count pass
     wfa::DevBuf ht[40];
+    int ht_src = 1;            // wfa_hit_rows_source: 1 = rows of the last hit pass, 2 = rows of the last gather
+    wfa::DevBuf gathered;      // rows the last wfa_rccl_gather_rows left on the root
+    int64_t gathered_n = -1;
     int64_t ht_n = -1, ht_groups = 0;
     int ht_kind = 0;  // 1 = event grouping, 2 = hit merge
     int64_t* ht_perm = nullptr;

@@ -218,6 +218,87 @@ __device__ __forceinline__ void int_band(bool positive, double b, double thr, do
     zlo = clamp_to_i32(tz - (double)margin);
 }
 
+// ---- threshold-hit helpers shared by the hit kernels (hit_finder.py:231-255, 329-413) ------------------------------
+struct HitCtx {
+    double baseline;
+    double thr;
+    int positive;
+    int L;
+    int max_len;
+    int le, re;
+};
+
+template <int SRC>
+__device__ __forceinline__ double hit_signal(const WaveSrc<SRC>& src, const HitCtx& hc, int i) {
+    // samples in [L, max_len) are the zero padding of the reference's dense matrix
+    // (records_view.py:229-253); signal = w - b for "positive", b - w otherwise (hit_finder.py:240)
+    const double w = (i < hc.L) ? src.at(i) : 0.0;
+    return hc.positive ? (w - hc.baseline) : (hc.baseline - w);
+}
+
+// order-independent variant (first maximum by explicit index comparison)
+struct HitAccAny {
+    double best;
+    int best_i;
+    double sum;
+    __device__ __forceinline__ void add(double s, int i) {
+        if (s > best || (s == best && i < best_i)) { best = s; best_i = i; }
+        sum += s > 0.0 ? s : 0.0;
+    }
+};
+
+struct HitAcc {
+    double best;
+    int best_i;
+    double sum;
+    __device__ __forceinline__ void add(double s, int i) {
+        if (s > best) { best = s; best_i = i; }  // ascending i: first maximum kept (np.argmax)
+        sum += s > 0.0 ? s : 0.0;                 // hit_finder.py:380
+    }
+};
+
+__device__ __forceinline__ void write_hit_row(uint8_t* __restrict__ out, int64_t h, const RecView& rec, int64_t r,
+                                              int L, int start, int end, int seg_start, int seg_end,
+                                              int pos, double best, double sum) {
+    const int dt_ns = rec.dt[r];
+    const double sip = (double)dt_ns * 1e3;  // hit_finder.py:382
+    const int64_t rise = (int64_t)(pos - start > 0 ? pos - start : 0) * dt_ns;
+    const int64_t fall = (int64_t)((end - 1) - pos > 0 ? (end - 1) - pos : 0) * dt_ns;
+    const int64_t gts = (int64_t)((double)rec.ts[r] + (double)pos * sip);  // :383-386
+    const int rl = L > 0 ? L : 0;
+    int es = seg_start < rl ? seg_start : rl;
+    int ee = seg_end < rl ? seg_end : rl;
+    if (ee < es) ee = es;
+    uint32_t* row = reinterpret_cast<uint32_t*>(out + h * 60);
+    put_i64(row, 0, (int64_t)pos);
+    put_f32(row, 2, (float)best);
+    put_f32(row, 3, (float)sum);
+    row[4] = (uint32_t)es;
+    row[5] = (uint32_t)ee;
+    put_f32(row, 6, (float)(double)(ee - es));
+    row[7] = (uint32_t)dt_ns;
+    put_f32(row, 8, (float)(double)rise);
+    put_f32(row, 9, (float)(double)fall);
+    put_i64(row, 10, gts);
+    row[12] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
+    put_i64(row, 13, rec.rid[r]);
+}
+
+// 64-bit values across the 8 lanes of a group with DPP only
+__device__ __forceinline__ double dpp_f64(double v, int ctrl_sel) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(uint32_t)(uint64_t)b, hi = (int)(uint32_t)((uint64_t)b >> 32);
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
+    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ int dpp_i32(int v, int ctrl_sel) {
+    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);                      // row_half_mirror
+}
+
 }  // namespace
 
 }  // namespace wfa

@@ -3,7 +3,12 @@
 // 10^5..10^7 hit rows, sorted with rocPRIM's stable radix sort (through hipCUB) and reduced with scans and
 // small per-group / per-cluster kernels.  Multi-key orders are built the way np.lexsort defines them:
 // stable sorts from the least significant key to the most significant one.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/block/block_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 #include "wfa_common.hpp"
 #include "wfa_numpy.hpp"
@@ -117,22 +122,22 @@ int lexsort(wfa_ctx* c, int64_t n, const uint64_t* const* keys, int n_keys, int6
     hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, p0);
     WFA_HIP_CHECK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
-    hipcub::DoubleBuffer<uint64_t> kb(k0, k1);
-    hipcub::DoubleBuffer<int64_t> pb(p0, p1);
+    rocprim::double_buffer<uint64_t> kb(k0, k1);
+    rocprim::double_buffer<int64_t> pb(p0, p1);
     size_t tmp_bytes = 0;
-    WFA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kb, pb, (int)n, 0, 64, c->stream));
+    WFA_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, pb, (size_t)n, 0u, 64u, c->stream));
     if ((rc = c->ht[S_CUB].ensure(tmp_bytes))) return rc;
     for (int k = n_keys - 1; k >= 0; --k) {
         const unsigned long long span = mm[2 * k + 1] - mm[2 * k];
         if (span == 0) continue;  // constant key: the order does not change
         const int bits = 64 - __builtin_clzll(span);
-        hipLaunchKernelGGL(k_gather_rebased, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, keys[k], pb.Current(),
-                           (uint64_t)mm[2 * k], kb.Current());
+        hipLaunchKernelGGL(k_gather_rebased, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, keys[k], pb.current(),
+                           (uint64_t)mm[2 * k], kb.current());
         size_t tb = c->ht[S_CUB].cap;
-        WFA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(c->ht[S_CUB].ptr, tb, kb, pb, (int)n, 0, bits, c->stream));
+        WFA_HIP_CHECK(rocprim::radix_sort_pairs(c->ht[S_CUB].ptr, tb, kb, pb, (size_t)n, 0u, (unsigned)bits, c->stream));
     }
     WFA_HIP_CHECK(hipGetLastError());
-    *perm_out = pb.Current();
+    *perm_out = pb.current();
     return WFA_OK;
 }
 
@@ -187,6 +192,48 @@ int upload_cols(wfa_ctx* c, int64_t n, const int64_t* ts, const int64_t* pos, co
         (rc = upload(c, S_DT, dt, n, &d_dt)) || (rc = upload(c, S_BOARD, board, n, &d_b)) ||
         (rc = upload(c, S_CHAN, chan, n, &d_c)) || (rc = upload(c, S_RID, rid, n, &d_rid)))
         return rc;
+    *h = HitCols{d_ts, d_pos, d_s, d_e, d_dt, d_b, d_c, d_rid};
+    return WFA_OK;
+}
+
+// Columns out of device-resident THRESHOLD_HIT_DTYPE rows (60 B packed: position i8 @0, edge_start i4 @16, edge_end i4
+// @20, dt i4 @28, timestamp i8 @40, board i2 @48, channel i2 @50, record_id i8 @52; cpu/hit_finder.py:33-49): the rows
+// of the last hit pass or of the last RCCL gather feed the hit-table stages without a host round trip.
+__global__ void k_unpack_hit_rows(int64_t n, const uint8_t* __restrict__ rows, int64_t* __restrict__ ts,
+                                  int64_t* __restrict__ pos, int32_t* __restrict__ s, int32_t* __restrict__ e,
+                                  int32_t* __restrict__ dt, int16_t* __restrict__ board, int16_t* __restrict__ chan,
+                                  int64_t* __restrict__ rid) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(rows + i * 60);
+    pos[i] = (int64_t)(((uint64_t)w[1] << 32) | w[0]);
+    s[i] = (int32_t)w[4];
+    e[i] = (int32_t)w[5];
+    dt[i] = (int32_t)w[7];
+    ts[i] = (int64_t)(((uint64_t)w[11] << 32) | w[10]);
+    board[i] = (int16_t)(w[12] & 0xffffu);
+    chan[i] = (int16_t)(w[12] >> 16);
+    rid[i] = (int64_t)(((uint64_t)w[14] << 32) | w[13]);
+}
+
+// resident rows selected by wfa_hit_rows_source: 1 = rows of the last hit pass, 2 = rows of the last RCCL gather
+int resident_cols(wfa_ctx* c, int64_t n, HitCols* h) {
+    const uint8_t* rows = nullptr;
+    int64_t have = -1;
+    if (c->ht_src == 2) { rows = c->gathered.as<uint8_t>(); have = c->gathered_n; }
+    else { rows = c->hit_out.as<uint8_t>(); have = c->pending ? -1 : c->n_hits; }
+    if (have < 0) return fail(WFA_E_STATE, "no device-resident hit rows (run a hit pass / a gather first)");
+    if (n != have) return fail(WFA_E_INVALID, "the resident hit table has %lld rows, the caller expects %lld", (long long)have, (long long)n);
+    int rc;
+    int64_t *d_ts, *d_pos, *d_rid;
+    int32_t *d_s, *d_e, *d_dt;
+    int16_t *d_b, *d_c;
+    if ((rc = slot(c, S_TS, n, &d_ts)) || (rc = slot(c, S_POS, n, &d_pos)) || (rc = slot(c, S_START, n, &d_s)) ||
+        (rc = slot(c, S_END, n, &d_e)) || (rc = slot(c, S_DT, n, &d_dt)) || (rc = slot(c, S_BOARD, n, &d_b)) ||
+        (rc = slot(c, S_CHAN, n, &d_c)) || (rc = slot(c, S_RID, n, &d_rid)))
+        return rc;
+    hipLaunchKernelGGL(k_unpack_hit_rows, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, rows, d_ts, d_pos, d_s, d_e, d_dt,
+                       d_b, d_c, d_rid);
     *h = HitCols{d_ts, d_pos, d_s, d_e, d_dt, d_b, d_c, d_rid};
     return WFA_OK;
 }
@@ -421,8 +468,8 @@ template <bool FILL>
 __global__ __launch_bounds__(kCsvNlBlock) void k_csv_newlines(int64_t n_bytes, const uint8_t* __restrict__ text,
                                                              const int64_t* __restrict__ block_start,
                                                              int64_t* __restrict__ block_count, int64_t* __restrict__ nl) {
-    using Scan = hipcub::BlockScan<int, kCsvNlBlock>;
-    __shared__ typename Scan::TempStorage tmp;
+    using Scan = rocprim::block_scan<int, kCsvNlBlock>;
+    __shared__ typename Scan::storage_type tmp;
     const int64_t a = ((int64_t)blockIdx.x * kCsvNlBlock + threadIdx.x) * 16;
     uint32_t m = 0;
     if (a < n_bytes) {  // the buffer is padded, the clip drops the padding
@@ -433,7 +480,7 @@ __global__ __launch_bounds__(kCsvNlBlock) void k_csv_newlines(int64_t n_bytes, c
         if (a + 16 > n_bytes) m &= (1u << (int)(n_bytes - a)) - 1u;
     }
     int before = 0, total = 0;
-    Scan(tmp).ExclusiveSum(__popc(m), before, total);
+    Scan().exclusive_scan(__popc(m), before, 0, total, tmp, rocprim::plus<int>());
     if (!FILL) {
         if (threadIdx.x == 0) block_count[blockIdx.x] = total;
         return;
@@ -584,6 +631,14 @@ static int use_device_ht(wfa_ctx* c) {
 
 extern "C" {
 
+int wfa_hit_rows_source(wfa_ctx* c, int which) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (which != 1 && which != 2) return fail(WFA_E_INVALID, "row source must be 1 (last hit pass) or 2 (last gather)");
+    c->ht_src = which;
+    return WFA_OK;
+}
+
 int wfa_group_hit_windows_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const int64_t* position,
                                 const int32_t* sample_start, const int32_t* sample_end, const int32_t* dt,
                                 const int16_t* board, const int16_t* channel, const int64_t* record_id,
@@ -595,10 +650,16 @@ int wfa_group_hit_windows_count(wfa_ctx* c, int64_t n, const int64_t* timestamp,
     if (time_window_ns < 0) return fail(WFA_E_INVALID, "time_window_ns must be >= 0");
     c->ht_n = -1;
     if (n == 0) { c->ht_n = 0; c->ht_groups = 0; c->ht_kind = 1; *n_events = 0; return WFA_OK; }
-    if (!timestamp || !position || !sample_start || !sample_end || !dt || !board || !channel || !record_id)
-        return fail(WFA_E_INVALID, "null column");
+    if (n > 0x7fffffffLL) return fail(WFA_E_LIMIT, "hit table has %lld rows; the device stages handle < 2^31", (long long)n);
     HitCols h{};
-    if ((rc = upload_cols(c, n, timestamp, position, sample_start, sample_end, dt, board, channel, record_id, &h))) return rc;
+    const bool resident = !timestamp && !position && !sample_start && !sample_end && !dt && !board && !channel && !record_id;
+    if (resident) {  // every column NULL: the device-resident rows (wfa_hit_rows_source); sample window = edge_start / edge_end
+        if ((rc = resident_cols(c, n, &h))) return rc;
+    } else {
+        if (!timestamp || !position || !sample_start || !sample_end || !dt || !board || !channel || !record_id)
+            return fail(WFA_E_INVALID, "null column");
+        if ((rc = upload_cols(c, n, timestamp, position, sample_start, sample_end, dt, board, channel, record_id, &h))) return rc;
+    }
     if ((abs_start_fix == nullptr) != (abs_end_fix == nullptr)) return fail(WFA_E_INVALID, "pass both abs_*_fix arrays or neither");
     double *fix0 = nullptr, *fix1 = nullptr;
     if (abs_start_fix && ((rc = upload(c, S_OUT6, abs_start_fix, n, &fix0)) || (rc = upload(c, S_OUT7, abs_end_fix, n, &fix1)))) return rc;
@@ -619,16 +680,16 @@ int wfa_group_hit_windows_count(wfa_ctx* c, int64_t n, const int64_t* timestamp,
     }
     hipLaunchKernelGGL(k_gather_f64, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, abs1, perm, ends);
     size_t tb = 0;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, tb, ends, run_max, MaxF64(), (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tb, ends, run_max, (size_t)n, MaxF64(), c->stream));
     size_t tb2 = 0;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb2, flag, incl, (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tb2, flag, incl, (size_t)n, rocprim::plus<int64_t>(), c->stream));
     if ((rc = c->ht[S_CUB].ensure(tb > tb2 ? tb : tb2))) return rc;
     tb = c->ht[S_CUB].cap;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(c->ht[S_CUB].ptr, tb, ends, run_max, MaxF64(), (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(c->ht[S_CUB].ptr, tb, ends, run_max, (size_t)n, MaxF64(), c->stream));
     hipLaunchKernelGGL(k_event_flags, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, abs0, perm, run_max,
                        time_window_ns * 1e3, flag);
     tb = c->ht[S_CUB].cap;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->ht[S_CUB].ptr, tb, flag, incl, (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(c->ht[S_CUB].ptr, tb, flag, incl, (size_t)n, rocprim::plus<int64_t>(), c->stream));
     int64_t n_ev = 0;
     WFA_HIP_CHECK(hipMemcpyAsync(&n_ev, incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     // event id as the new primary key; k_dt's buffer is free again (k_chan carries dt)
@@ -680,10 +741,16 @@ int wfa_hit_merge_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const i
     if (n < 0 || !n_clusters) return fail(WFA_E_INVALID, "bad arguments");
     c->ht_n = -1;
     if (n == 0) { c->ht_n = 0; c->ht_groups = 0; c->ht_kind = 2; *n_clusters = 0; return WFA_OK; }
-    if (!timestamp || !position || !edge_start || !edge_end || !dt || !board || !channel)
-        return fail(WFA_E_INVALID, "null column");
+    if (n > 0x7fffffffLL) return fail(WFA_E_LIMIT, "hit table has %lld rows; the device stages handle < 2^31", (long long)n);
     HitCols h{};
-    if ((rc = upload_cols(c, n, timestamp, position, edge_start, edge_end, dt, board, channel, timestamp, &h))) return rc;
+    const bool resident = !timestamp && !position && !edge_start && !edge_end && !dt && !board && !channel;
+    if (resident) {  // every column NULL: the device-resident rows (wfa_hit_rows_source)
+        if ((rc = resident_cols(c, n, &h))) return rc;
+    } else {
+        if (!timestamp || !position || !edge_start || !edge_end || !dt || !board || !channel)
+            return fail(WFA_E_INVALID, "null column");
+        if ((rc = upload_cols(c, n, timestamp, position, edge_start, edge_end, dt, board, channel, timestamp, &h))) return rc;
+    }
     double *abs0, *abs1, *s0, *s1;
     uint64_t *k_abs, *k_chan, *sg;
     int32_t* sdt;
@@ -709,15 +776,15 @@ int wfa_hit_merge_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const i
     const double gap_ps = merge_gap_ns * 1e3;
     hipLaunchKernelGGL(k_merge_segin, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, s1, sg, seg_in);
     size_t tb = 0, tb_seg = 0;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, tb_seg, seg_in, seg_run, SegMaxOp(), (int)n, c->stream));
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tb, flag, incl, (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tb_seg, seg_in, seg_run, (size_t)n, SegMaxOp(), c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tb, flag, incl, (size_t)n, rocprim::plus<int64_t>(), c->stream));
     if ((rc = c->ht[S_CUB].ensure(tb > tb_seg ? tb : tb_seg))) return rc;
     tb_seg = c->ht[S_CUB].cap;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(c->ht[S_CUB].ptr, tb_seg, seg_in, seg_run, SegMaxOp(), (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(c->ht[S_CUB].ptr, tb_seg, seg_in, seg_run, (size_t)n, SegMaxOp(), c->stream));
     hipLaunchKernelGGL(k_merge_chain, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, s0, s1, sdt, sg, seg_run, do_merge,
                        gap_ps, max_total_width_ns * 1e3, flag);
     tb = c->ht[S_CUB].cap;
-    WFA_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(c->ht[S_CUB].ptr, tb, flag, incl, (int)n, c->stream));
+    WFA_HIP_CHECK(rocprim::inclusive_scan(c->ht[S_CUB].ptr, tb, flag, incl, (size_t)n, rocprim::plus<int64_t>(), c->stream));
     int64_t n_cl = 0;
     WFA_HIP_CHECK(hipMemcpyAsync(&n_cl, incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -942,9 +1009,9 @@ int wfa_csv_decode_count(wfa_ctx* c, const uint8_t* text, int64_t n_bytes, int d
     hipLaunchKernelGGL((k_csv_newlines<false>), dim3((unsigned)nb), dim3(kCsvNlBlock), 0, c->stream, n_bytes, d_text,
                        (const int64_t*)nullptr, d_bc, (int64_t*)nullptr);
     size_t tmp = 0;
-    WFA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_bc, d_bs, (int)nb, c->stream));
+    WFA_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp, d_bc, d_bs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), c->stream));
     if ((rc = c->ht[S_CUB].ensure(tmp))) return rc;
-    WFA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->ht[S_CUB].ptr, tmp, d_bc, d_bs, (int)nb, c->stream));
+    WFA_HIP_CHECK(rocprim::exclusive_scan(c->ht[S_CUB].ptr, tmp, d_bc, d_bs, (int64_t)0, (size_t)nb, rocprim::plus<int64_t>(), c->stream));
     int64_t last[2] = {0, 0};
     WFA_HIP_CHECK(hipMemcpyAsync(&last[0], d_bs + nb - 1, 8, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipMemcpyAsync(&last[1], d_bc + nb - 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -967,9 +1034,9 @@ int wfa_csv_decode_count(wfa_ctx* c, const uint8_t* text, int64_t n_bytes, int d
         hipLaunchKernelGGL(k_csv_count, dim3((unsigned)n_lines), dim3(64), 0, c->stream, n_lines, d_text, d_rs, d_re,
                            (uint8_t)delimiter, samples_start, d_nf, d_ns);
         size_t tb = 0;
-        WFA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_ns, d_so, (int)n_lines, c->stream));
+        WFA_HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, d_ns, d_so, (int64_t)0, (size_t)n_lines, rocprim::plus<int64_t>(), c->stream));
         if ((rc = c->ht[S_CUB].ensure(tb))) return rc;
-        WFA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(c->ht[S_CUB].ptr, tb, d_ns, d_so, (int)n_lines, c->stream));
+        WFA_HIP_CHECK(rocprim::exclusive_scan(c->ht[S_CUB].ptr, tb, d_ns, d_so, (int64_t)0, (size_t)n_lines, rocprim::plus<int64_t>(), c->stream));
     }
     WFA_HIP_CHECK(hipGetLastError());
     if ((rc = t.end("csv: index rows + count fields"))) return rc;

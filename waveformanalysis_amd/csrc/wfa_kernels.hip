@@ -64,23 +64,6 @@ __global__ __launch_bounds__(kBlock) void k_savgol(PoolView pool, RecView rec, S
 // Hit rows go to chunked temporary storage (one atomic per chunk, not per record); a scan over
 // the per-record counts and a gather kernel then produce the (record, start)-ordered output.
 
-struct HitCtx {
-    double baseline;
-    double thr;
-    int positive;
-    int L;
-    int max_len;
-    int le, re;
-};
-
-template <int SRC>
-__device__ __forceinline__ double hit_signal(const WaveSrc<SRC>& src, const HitCtx& hc, int i) {
-    // samples in [L, max_len) are the zero padding of the reference's dense matrix
-    // (records_view.py:229-253); signal = w - b for "positive", b - w otherwise (hit_finder.py:240)
-    const double w = (i < hc.L) ? src.at(i) : 0.0;
-    return hc.positive ? (w - hc.baseline) : (hc.baseline - w);
-}
-
 template <int SRC, bool FUSED_BASELINE>
 __global__ __launch_bounds__(kBlock) void k_hits(PoolView pool, RecView rec, SgParams sg,
                                                  HitParams hp) {
@@ -634,168 +617,6 @@ __device__ __attribute__((noinline)) void span_phase0(const PoolView& pool, cons
     tab->bl[lane] = baseline; tab->thr[lane] = thr;
 }
 
-template <int W, bool FUSED_BASELINE>
-__global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span(PoolView pool, RecView rec, SgParams sg,
-                                                         MaskParams mp, SpanParams sp) {
-    constexpr int H = W / 2;
-    constexpr int NP = H + 1;
-    static_assert(W % 2 == 1 && W >= 3 && W <= 15, "halo must fit in the adjacent lane");
-    __shared__ SpanTable s_tab[kWavesPerBlock];
-    __shared__ int32_t etab[2 * H * W];
-    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
-    __syncthreads();
-    const int lane = lane_id();
-    const int wv = wave_in_block();
-    SpanTable* tab = &s_tab[wv];
-    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-    const int L = sp.L;
-    const bool positive = sp.positive != 0;
-
-    uint32_t cpm[NP];
-#pragma unroll
-    for (int m = 0; m < NP; ++m) {
-        int n0 = sg.itab[2 * m];
-        int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
-        if (positive) { n0 = -n0; n1 = -n1; }  // Z = -(n.x - bias)
-        cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
-    }
-    const uint32_t fill_raw = positive ? 0u : 0xffffffffu;
-    const uint32_t fillb = fill_raw ^ 0x80008000u;
-
-    for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
-        const int64_t r0 = span * sp.rs;
-        const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
-        const int64_t g_base = sp.off0 + r0 * L;  // pool index of the span's first sample (multiple of 8)
-
-        span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
-                                       32768.0 * (double)sg.den, tab);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-        // ================= phase 1: tiles over the span's sample stream =================
-        const int span_samples = nrec * L;
-        const int T = (span_samples + 511) / 512;
-        // sp.dbg (measurement only): bit1 = every span streams span 0's samples (cache resident)
-        const uint16_t* __restrict__ span_ptr = pool.u16 + ((sp.dbg & 2) ? sp.off0 : g_base);
-        const int last_chunk_pos = span_samples - 8;  // loads beyond the span re-read its last chunk
-        auto tile_at = [&](int t) {
-            int pos = t * 512 + lane * 8;
-            pos = pos < last_chunk_pos ? pos : last_chunk_pos;
-            const uint4 v = *reinterpret_cast<const uint4*>(span_ptr + pos);
-            Tile x;
-            x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
-            return x;
-        };
-        int rl = (lane * 8) / L;        // record (within the span) of this lane's chunk
-        int i0 = lane * 8 - rl * L;     // position of the chunk inside its record (multiple of 8)
-        uint32_t p0 = fillb, p1 = fillb, p2 = fillb, p3 = fillb;
-        uint32_t carry_msb = 0;
-        uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
-        int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);       // byte of this lane's chunk in the span's bitmap
-        const int bm_wrap = (int)sp.bm_stride - (L >> 3);      // added when the lane moves to the next record
-
-        auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
-            const bool in_span = t * 512 + lane * 8 < span_samples;
-            const int rli = in_span ? rl : 0;
-            const int zhi = in_span ? tab->zhi[rli] : INT32_MIN;
-
-            uint32_t E[12];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) E[4 + k] = cur.d[k] ^ 0x80008000u;
-            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80008000u;
-            const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80008000u;
-            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80008000u;
-            const uint32_t n3 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[3], 0) ^ 0x80008000u;
-            E[0] = dpp_from_prev_lane(p0, E[4]);
-            E[1] = dpp_from_prev_lane(p1, E[5]);
-            E[2] = dpp_from_prev_lane(p2, E[6]);
-            E[3] = dpp_from_prev_lane(p3, E[7]);
-            E[8] = dpp_from_next_lane(n0, E[4]);
-            E[9] = dpp_from_next_lane(n1, E[5]);
-            E[10] = dpp_from_next_lane(n2, E[6]);
-            E[11] = dpp_from_next_lane(n3, E[7]);
-            int Z[8];
-            if (sp.dbg & 1) {  // measurement only: no filter arithmetic
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Z[j] = (int)(E[2 + j] >> 1) + 0x40000000;
-            } else {
-                sg_chunk_numerators<W>(E, cpm, Z);
-            }
-
-            // candidates: 8 compares into lane masks, OR-ed on the scalar unit
-            uint64_t cm[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cm[j] = __ballot(Z[j] < zhi);
-            const uint64_t any_c = cm[0] | cm[1] | cm[2] | cm[3] | cm[4] | cm[5] | cm[6] | cm[7];
-            const bool first = i0 == 0, last = i0 == L - 8;
-            const uint64_t edge_lanes = __ballot(in_span && (first || last));
-            uint32_t byte = 0;
-            if (any_c != 0 || edge_lanes != 0) {
-                // interior outputs of this chunk: all 8, except next to a record boundary
-                const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
-                const int zlo = tab->zlo[rli];
-                uint32_t border = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool c = Z[j] < zhi;
-                    byte |= (uint32_t)c << j;
-                    border |= (uint32_t)(c && Z[j] > zlo) << j;
-                }
-                byte &= vb;
-                border &= vb;
-                if (__ballot(border != 0) != 0) {
-                    if (border) {  // rare: the reference's float64 arithmetic decides
-                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
-                        const double baseline = tab->bl[rli], thr = tab->thr[rli];
-                        while (border) {
-                            const int j = __ffs((int)border) - 1;
-                            border &= border - 1;
-                            const double w = src.at(i0 + j);
-                            const double sig = positive ? (w - baseline) : (baseline - w);
-                            if (!(sig >= thr)) byte &= ~(1u << j);
-                        }
-                    }
-                }
-                if (in_span && (first || last)) {
-                    const uint32_t ebr = (uint32_t)tab->eb[rli];
-                    byte |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (8 - H)) & 0xffu;
-                }
-                if (__ballot(byte != 0) != 0) {
-                    // run starts: a set bit whose predecessor (same record) is clear
-                    uint32_t prevb = dpp_from_prev_lane(carry_msb << 7, byte);
-                    if (first) prevb = 0;
-                    const uint32_t starts = byte & ~((byte << 1) | (prevb >> 7)) & 0xffu;
-                    if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
-                }
-            }
-            if (in_span) bm_span[bm_pos] = (uint8_t)byte;
-            carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
-            p0 = (uint32_t)__builtin_amdgcn_readlane((int)E[4], 63);
-            p1 = (uint32_t)__builtin_amdgcn_readlane((int)E[5], 63);
-            p2 = (uint32_t)__builtin_amdgcn_readlane((int)E[6], 63);
-            p3 = (uint32_t)__builtin_amdgcn_readlane((int)E[7], 63);
-            i0 += 512;
-            bm_pos += 64;
-            while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
-        };
-        // ring of 4 tiles, 3 loads in flight; unrolled by 4 so the ring never moves registers
-        Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
-        int t = 0;
-        for (; t + 4 <= T; t += 4) {
-            rd = tile_at(t + 3); do_tile(t, ra, rb);
-            ra = tile_at(t + 4); do_tile(t + 1, rb, rc);
-            rb = tile_at(t + 5); do_tile(t + 2, rc, rd);
-            rc = tile_at(t + 6); do_tile(t + 3, rd, ra);
-        }
-        if (t < T) { rd = tile_at(t + 3); do_tile(t, ra, rb); ++t; }
-        if (t < T) { do_tile(t, rb, rc); ++t; }
-        if (t < T) { do_tile(t, rc, rd); ++t; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < nrec) mp.rec_nhits[r0 + lane] = tab->nr[lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-}
-
 // ---- A (span mode, 16 samples per lane): same kernel with 1024-sample tiles ---------------------------
 // The dot2 kernel is VALU-issue bound (~4.2 cycles per wave64 op, tools/valu_rate.hip), and about a third
 // of its instructions are per-tile bookkeeping (halo exchange, record tracking, address math, store).
@@ -861,16 +682,12 @@ __global__ __launch_bounds__(kBlock, WFA_SPAN_WAVES) void k_sg_mask_span16(PoolV
         const int64_t r0 = span * sp.rs;
         const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
         const int64_t g_base = sp.off0 + r0 * S;
-        if (sp.dbg & 8) {  // measurement only: no per-record phase
-            tab->zhi[lane] = INT32_MIN; tab->zlo[lane] = INT32_MIN; tab->eb[lane] = 0; tab->nr[lane] = 0;
-        } else {
-            span_phase0<W, FUSED_BASELINE, PADDED>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
-                                                   32768.0 * (double)sg.den, tab, S);
-        }
+        span_phase0<W, FUSED_BASELINE, PADDED>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive,
+                                               32768.0 * (double)sg.den, tab, S);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
         const int span_samples = nrec * S;             // multiple of 16
-        const int T = (sp.dbg & 4) ? 0 : (span_samples + 1023) / 1024;  // dbg 4: no tile loop
+        const int T = (span_samples + 1023) / 1024;
         const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
         const int last_pos = span_samples - 16;
         auto tile_at = [&](int t) {
@@ -1183,190 +1000,8 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
     }
 }
 
-// ---- A (span mode, matrix cores): the FIR as a banded matrix product -----------------------------------
-// Same contract as k_sg_mask_span, for |n_k| <= 127.  Measured: the integer VALU issues one wave64 op
-// per ~4.2 cycles (tools/valu_rate.hip), so 48 dot2 + 9 perm + 8 mov per tile make the dot2 kernel
-// VALU-bound at ~0.33 of HBM peak.  Here the 11-tap sums run on v_mfma_i32_16x16x64_i8, D = A x B with
-//   B (64 x 16 bytes) = the wave's 64 loaded chunks exactly as they sit in registers: lane l = 16g + c
-//                       holds k-quarter g of column c, i.e. chunk l (bytes biased by -128: one xor/dword),
-//   A (16 x 64)       = host-built band matrix: row 4g + i reads only k-quarter g and carries the taps
-//                       of output i on the low-byte (P) or high-byte (Q) positions,
-//   D (16 x 16 int32) : lane l = 16g + c receives rows 4g + i, i = 0..3  ==  outputs 0..3 of ITS OWN chunk.
-// The same A applied to the data shifted by 4 samples (registers [d2,d3,next.d0,next.d1]: no instruction)
-// gives outputs 4..7.  Three shifts (previous / own / next chunk, halo over DPP) x {P,Q} x {0..3, 4..7}
-// = 12 MFMAs per tile; numerator Z = P + 256 Q (+ a constant folded into the band).  Everything after
-// the numerators is identical to k_sg_mask_span.
 typedef int wfa_v4i __attribute__((ext_vector_type(4)));
 
-template <int W, bool FUSED_BASELINE>
-__global__ __launch_bounds__(kBlock) void k_sg_mask_span_mfma(PoolView pool, RecView rec, SgParams sg,
-                                                              MaskParams mp, SpanParams sp) {
-    constexpr int H = W / 2;
-    __shared__ SpanTable s_tab[kWavesPerBlock];
-    __shared__ int32_t etab[2 * H * W];
-    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
-    __syncthreads();
-    const int lane = lane_id();
-    const int wv = wave_in_block();
-    SpanTable* tab = &s_tab[wv];
-    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wv);
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-    const int L = sp.L;
-    const bool positive = sp.positive != 0;
-
-    // band matrices in A-operand layout: [polarity][shift prev/own/next][part P/Q][lane] x 16 B
-    const wfa_v4i* __restrict__ atab = reinterpret_cast<const wfa_v4i*>(sg.mfma_tab) + (positive ? 6 * 64 : 0);
-    wfa_v4i A[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) A[k] = atab[k * 64 + lane];
-    const double bias = 32896.0 * (double)sg.den;  // 128 * (1 + 256) * sum(n)
-    const uint32_t fill_raw = positive ? 0u : 0xffffffffu;
-    const uint32_t fillb = fill_raw ^ 0x80808080u;
-
-    for (int64_t span = wave0; span < sp.n_spans; span += nwaves) {
-        const int64_t r0 = span * sp.rs;
-        const int nrec = (int)((rec.R - r0) < sp.rs ? (rec.R - r0) : sp.rs);
-        const int64_t g_base = sp.off0 + r0 * L;
-        span_phase0<W, FUSED_BASELINE>(pool, rec, sg, mp, etab, g_base, r0, nrec, L, positive, bias, tab);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-        const int span_samples = nrec * L;
-        const int T = (span_samples + 511) / 512;
-        const uint16_t* __restrict__ span_ptr = pool.u16 + g_base;
-        const int last_chunk_pos = span_samples - 8;
-        auto tile_at = [&](int t) {
-            int pos = t * 512 + lane * 8;
-            pos = pos < last_chunk_pos ? pos : last_chunk_pos;
-            const uint4 v = *reinterpret_cast<const uint4*>(span_ptr + pos);
-            Tile x;
-            x.d[0] = v.x; x.d[1] = v.y; x.d[2] = v.z; x.d[3] = v.w;
-            return x;
-        };
-        int rl = (lane * 8) / L;
-        int i0 = lane * 8 - rl * L;
-        uint32_t p1 = fillb, p2 = fillb, p3 = fillb;
-        uint32_t carry_msb = 0;
-        uint8_t* __restrict__ bm_span = mp.bitmap + sp.bm_off0 + r0 * sp.bm_stride;
-        int bm_pos = rl * (int)sp.bm_stride + (i0 >> 3);
-        const int bm_wrap = (int)sp.bm_stride - (L >> 3);
-
-        auto do_tile = [&](int t, const Tile& cur, const Tile& nxt) {
-            const bool in_span = t * 512 + lane * 8 < span_samples;
-            const int rli = in_span ? rl : 0;
-            const int zhi = in_span ? tab->zhi[rli] : INT32_MIN;
-
-            // R[0..3] previous chunk, R[4..7] own, R[8..11] next (dwords, bytes biased)
-            uint32_t R[12];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) R[4 + k] = cur.d[k] ^ 0x80808080u;
-            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[0], 0) ^ 0x80808080u;
-            const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[1], 0) ^ 0x80808080u;
-            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nxt.d[2], 0) ^ 0x80808080u;
-            R[0] = R[4];  // samples -8,-7 never enter a window (H <= 7): rows of A are zero there
-            R[1] = dpp_from_prev_lane(p1, R[5]);
-            R[2] = dpp_from_prev_lane(p2, R[6]);
-            R[3] = dpp_from_prev_lane(p3, R[7]);
-            R[8] = dpp_from_next_lane(n0, R[4]);
-            R[9] = dpp_from_next_lane(n1, R[5]);
-            R[10] = dpp_from_next_lane(n2, R[6]);
-            R[11] = R[7];  // samples 14,15 of the next chunk: zero rows as well
-            const wfa_v4i zero = {0, 0, 0, 0};
-            auto opnd = [&](int first) {
-                wfa_v4i v;
-                v[0] = (int)R[first]; v[1] = (int)R[first + 1];
-                v[2] = (int)R[first + 2 < 12 ? first + 2 : 11]; v[3] = (int)R[first + 3 < 12 ? first + 3 : 11];
-                return v;
-            };
-            // outputs 0..3: data windows R[0:3], R[4:7], R[8:11]; outputs 4..7: the same shifted by 4 samples
-            const wfa_v4i b_prev = opnd(0), b_own = opnd(4), b_next = opnd(8);
-            const wfa_v4i c_prev = opnd(2), c_own = opnd(6), c_next = opnd(10);
-            wfa_v4i P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], b_prev, zero, 0, 0, 0);
-            wfa_v4i Q1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], b_prev, zero, 0, 0, 0);
-            wfa_v4i P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], c_prev, zero, 0, 0, 0);
-            wfa_v4i Q2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], c_prev, zero, 0, 0, 0);
-            P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], b_own, P1, 0, 0, 0);
-            Q1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], b_own, Q1, 0, 0, 0);
-            P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], c_own, P2, 0, 0, 0);
-            Q2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], c_own, Q2, 0, 0, 0);
-            P1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[4], b_next, P1, 0, 0, 0);
-            Q1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[5], b_next, Q1, 0, 0, 0);
-            P2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[4], c_next, P2, 0, 0, 0);
-            Q2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[5], c_next, Q2, 0, 0, 0);
-            int Z[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Z[i] = P1[i] + (Q1[i] << 8);
-                Z[4 + i] = P2[i] + (Q2[i] << 8);
-            }
-
-            uint64_t cm[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cm[j] = __ballot(Z[j] < zhi);
-            const uint64_t any_c = cm[0] | cm[1] | cm[2] | cm[3] | cm[4] | cm[5] | cm[6] | cm[7];
-            const bool first = i0 == 0, last = i0 == L - 8;
-            const uint64_t edge_lanes = __ballot(in_span && (first || last));
-            uint32_t byte = 0;
-            if (any_c != 0 || edge_lanes != 0) {
-                const uint32_t vb = (first ? (0xffu << H) & 0xffu : 0xffu) & (last ? 0xffu >> H : 0xffu);
-                const int zlo = tab->zlo[rli];
-                uint32_t border = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool c = Z[j] < zhi;
-                    byte |= (uint32_t)c << j;
-                    border |= (uint32_t)(c && Z[j] > zlo) << j;
-                }
-                byte &= vb;
-                border &= vb;
-                if (__ballot(border != 0) != 0) {
-                    if (border) {  // rare: the reference's float64 arithmetic decides
-                        WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, g_base + (int64_t)rli * L, L);
-                        const double baseline = tab->bl[rli], thr = tab->thr[rli];
-                        while (border) {
-                            const int j = __ffs((int)border) - 1;
-                            border &= border - 1;
-                            const double w = src.at(i0 + j);
-                            const double sig = positive ? (w - baseline) : (baseline - w);
-                            if (!(sig >= thr)) byte &= ~(1u << j);
-                        }
-                    }
-                }
-                if (in_span && (first || last)) {
-                    const uint32_t ebr = (uint32_t)tab->eb[rli];
-                    byte |= first ? (ebr & ((1u << H) - 1u)) : ((ebr >> H) << (8 - H)) & 0xffu;
-                }
-                if (__ballot(byte != 0) != 0) {
-                    uint32_t prevb = dpp_from_prev_lane(carry_msb << 7, byte);
-                    if (first) prevb = 0;
-                    const uint32_t starts = byte & ~((byte << 1) | (prevb >> 7)) & 0xffu;
-                    if (starts) atomicAdd(&tab->nr[rli], __popc(starts));
-                }
-            }
-            if (in_span) bm_span[bm_pos] = (uint8_t)byte;
-            carry_msb = ((uint32_t)__builtin_amdgcn_readlane((int)byte, 63) >> 7) & 1u;
-            p1 = (uint32_t)__builtin_amdgcn_readlane((int)R[5], 63);
-            p2 = (uint32_t)__builtin_amdgcn_readlane((int)R[6], 63);
-            p3 = (uint32_t)__builtin_amdgcn_readlane((int)R[7], 63);
-            i0 += 512;
-            bm_pos += 64;
-            while (i0 >= L) { i0 -= L; ++rl; bm_pos += bm_wrap; }
-        };
-        Tile ra = tile_at(0), rb = tile_at(1), rc = tile_at(2), rd;
-        int t = 0;
-        for (; t + 4 <= T; t += 4) {
-            rd = tile_at(t + 3); do_tile(t, ra, rb);
-            ra = tile_at(t + 4); do_tile(t + 1, rb, rc);
-            rb = tile_at(t + 5); do_tile(t + 2, rc, rd);
-            rc = tile_at(t + 6); do_tile(t + 3, rd, ra);
-        }
-        if (t < T) { rd = tile_at(t + 3); do_tile(t, ra, rb); ++t; }
-        if (t < T) { do_tile(t, rb, rc); ++t; }
-        if (t < T) { do_tile(t, rc, rd); ++t; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < nrec) mp.rec_nhits[r0 + lane] = tab->nr[lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-}
 
 // ---- B1: runs of set bits of every record -> hit descriptors ----------------------------------------
 // desc = (record, start, end, flag); flag 0: record filtered with the full SG window (integer row
@@ -1437,54 +1072,6 @@ __global__ __launch_bounds__(kRunsBlock) void k_hit_runs(RecView rec, const uint
 }
 
 // ---- B2: hit rows ---------------------------------------------------------------------------------------
-// order-independent variant (first maximum by explicit index comparison)
-struct HitAccAny {
-    double best;
-    int best_i;
-    double sum;
-    __device__ __forceinline__ void add(double s, int i) {
-        if (s > best || (s == best && i < best_i)) { best = s; best_i = i; }
-        sum += s > 0.0 ? s : 0.0;
-    }
-};
-
-struct HitAcc {
-    double best;
-    int best_i;
-    double sum;
-    __device__ __forceinline__ void add(double s, int i) {
-        if (s > best) { best = s; best_i = i; }  // ascending i: first maximum kept (np.argmax)
-        sum += s > 0.0 ? s : 0.0;                 // hit_finder.py:380
-    }
-};
-
-__device__ __forceinline__ void write_hit_row(uint8_t* __restrict__ out, int64_t h, const RecView& rec, int64_t r,
-                                              int L, int start, int end, int seg_start, int seg_end,
-                                              int pos, double best, double sum) {
-    const int dt_ns = rec.dt[r];
-    const double sip = (double)dt_ns * 1e3;  // hit_finder.py:382
-    const int64_t rise = (int64_t)(pos - start > 0 ? pos - start : 0) * dt_ns;
-    const int64_t fall = (int64_t)((end - 1) - pos > 0 ? (end - 1) - pos : 0) * dt_ns;
-    const int64_t gts = (int64_t)((double)rec.ts[r] + (double)pos * sip);  // :383-386
-    const int rl = L > 0 ? L : 0;
-    int es = seg_start < rl ? seg_start : rl;
-    int ee = seg_end < rl ? seg_end : rl;
-    if (ee < es) ee = es;
-    uint32_t* row = reinterpret_cast<uint32_t*>(out + h * 60);
-    put_i64(row, 0, (int64_t)pos);
-    put_f32(row, 2, (float)best);
-    put_f32(row, 3, (float)sum);
-    row[4] = (uint32_t)es;
-    row[5] = (uint32_t)ee;
-    put_f32(row, 6, (float)(double)(ee - es));
-    row[7] = (uint32_t)dt_ns;
-    put_f32(row, 8, (float)(double)rise);
-    put_f32(row, 9, (float)(double)fall);
-    put_i64(row, 10, gts);
-    row[12] = (uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16);
-    put_i64(row, 13, rec.rid[r]);
-}
-
 // literal path: one lane per hit, float64 code of the reference for every window sample.
 // only_flagged: process descriptors with flag != 0 (the fast kernel did the others).
 template <int SRC>
@@ -1510,21 +1097,6 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecV
     HitAcc acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
     for (int i = seg_start; i < seg_end; ++i) acc.add(hit_signal<SRC>(src, hc, i), i);
     write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
-}
-
-// 64-bit values across the 8 lanes of a group with DPP only
-__device__ __forceinline__ double dpp_f64(double v, int ctrl_sel) {
-    const long long b = __double_as_longlong(v);
-    int lo = (int)(uint32_t)(uint64_t)b, hi = (int)(uint32_t)((uint64_t)b >> 32);
-    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false); }
-    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false); }
-    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false); }
-    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
-}
-__device__ __forceinline__ int dpp_i32(int v, int ctrl_sel) {
-    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);                      // row_half_mirror
 }
 
 // fast path: 8 lanes per hit.  Lane q of a group loads the aligned 16-byte chunk (c - 1 + q); lanes
@@ -3028,38 +2600,6 @@ hipError_t launch_savgol_span(hipStream_t st, const PoolView& pool, const RecVie
     return hipGetLastError();
 }
 
-bool sg_mask_mfma_supported(const SgParams& sg, int L) {
-    (void)L;
-    return sg.mfma_tab != nullptr && sg.W >= 5 && sg.W <= 15;
-}
-
-hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
-                                    const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
-    int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t resident = 256 * WFA_SPAN_WAVES;
-    if (g < 1) g = 1;
-    if (g > resident) g = resident;
-    const int grid = (int)g;
-#define WFA_SPANM(WW)                                                                                                  \
-    case WW:                                                                                                           \
-        if (fused_baseline)                                                                                            \
-            hipLaunchKernelGGL((k_sg_mask_span_mfma<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp);  \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_sg_mask_span_mfma<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp); \
-        break;
-    switch (sg.W) {
-        WFA_SPANM(5)
-        WFA_SPANM(7)
-        WFA_SPANM(9)
-        WFA_SPANM(11)
-        WFA_SPANM(13)
-        WFA_SPANM(15)
-        default: return hipErrorInvalidValue;
-    }
-#undef WFA_SPANM
-    return hipGetLastError();
-}
-
 // uniform records whose length is not a multiple of 16: the same kernel on the padded shadow layout (stride
 // roundup16(L)).  The last chunk of a slot must hold the H right-edge samples: L % 16 >= H.
 bool sg_mask_span16_padded_supported(const SgParams& sg, int32_t L) {
@@ -3136,35 +2676,6 @@ hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const Pool
     }
 #undef WFA_SPAN16_LAUNCH
 #undef WFA_SPAN16
-    return hipGetLastError();
-}
-
-hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
-                               const SgParams& sg, const MaskParams& mp, const SpanParams& sp) {
-    // persistent waves: exactly the resident set (256 CUs x WFA_SPAN_WAVES waves/SIMD), spans are dealt
-    // round-robin, so a wave never starts a second "round" of blocks
-    int64_t g = (sp.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t resident = 256 * WFA_SPAN_WAVES;
-    if (g < 1) g = 1;
-    if (g > resident) g = resident;
-    const int grid = (int)g;
-#define WFA_SPAN(WW)                                                                                              \
-    case WW:                                                                                                      \
-        if (fused_baseline)                                                                                       \
-            hipLaunchKernelGGL((k_sg_mask_span<WW, true>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp);  \
-        else                                                                                                      \
-            hipLaunchKernelGGL((k_sg_mask_span<WW, false>), dim3(grid), dim3(kBlock), 0, st, pool, rec, sg, mp, sp); \
-        break;
-    switch (sg.W) {
-        WFA_SPAN(5)
-        WFA_SPAN(7)
-        WFA_SPAN(9)
-        WFA_SPAN(11)
-        WFA_SPAN(13)
-        WFA_SPAN(15)
-        default: return hipErrorInvalidValue;
-    }
-#undef WFA_SPAN
     return hipGetLastError();
 }
 

@@ -44,7 +44,6 @@ struct SgParams {
     double rden, rden_edge;
     int32_t margin;       // numerator units covering one float32 ulp of y (candidate band half-width)
     int32_t margin_edge;  // same for the edge projection rows (den_edge)
-    const int8_t* mfma_tab;  // band matrices for v_mfma_i32_16x16x64_i8 (2 x 12 x 64 x 16 B) or nullptr
 };
 
 struct HitParams {
@@ -77,7 +76,6 @@ struct SpanParams {
     int64_t n_spans;
     int64_t bm_off0;   // bitmap byte offset of record 0
     int64_t bm_stride; // bitmap bytes per record
-    int32_t dbg;       // measurement knobs (0 in production)
     int32_t S = 0;     // record stride in samples (0 = L: packed records; span16 / savgol_span: multiple of 16, S - L < 16)
     int64_t out_off0 = 0;  // k_savgol_span on the padded layout: pool position of record 0 in the packed output
 };
@@ -201,16 +199,11 @@ hipError_t launch_pad_rows(hipStream_t st, const uint16_t* src, int64_t off0, in
                            uint16_t* dst, int64_t* dst_off);
 hipError_t launch_sg_mask(hipStream_t st, bool fused_baseline, int max_len, const PoolView& pool,
                           const RecView& rec, const SgParams& sg, const MaskParams& mp);
-hipError_t launch_sg_mask_span(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
-                               const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 hipError_t launch_savgol_span(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
                               const SpanParams& sp, float* out);
 bool sg_mask_span16_supported(const SgParams& sg, int L);
 hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
-bool sg_mask_mfma_supported(const SgParams& sg, int L);
-hipError_t launch_sg_mask_span_mfma(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
-                                    const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl);
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a);
 hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,

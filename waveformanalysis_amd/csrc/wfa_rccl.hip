@@ -85,7 +85,9 @@ int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t r
     const int n = c->n_ranks;
 
     const uint8_t* d_rows = nullptr;
-    DevBuf staged, d_all;
+    DevBuf staged;
+    DevBuf& d_all = c->gathered;  // stays resident on the root: the hit-table stages read it (wfa_hit_rows_source(ctx, 2))
+    c->gathered_n = -1;
     int rc = WFA_OK;
     if (rows == nullptr) {
         if (c->n_hits < 0) return fail(WFA_E_STATE, "no hit pass has been run");
@@ -101,8 +103,7 @@ int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t r
     int64_t total = 0;
     for (int r = 0; r < n; ++r) total += counts[r];
     if (c->rank == root) {
-        if (total > 0 && !out) { staged.release(); return fail(WFA_E_INVALID, "out is null on the root"); }
-        if ((rc = d_all.ensure((size_t)total * row_bytes))) { staged.release(); return rc; }
+        if ((rc = d_all.ensure((size_t)total * row_bytes + 64))) { staged.release(); return rc; }
     }
     ncclResult_t nr = ncclGroupStart();
     if (nr == ncclSuccess && n_rows > 0)
@@ -119,12 +120,12 @@ int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t r
     ncclResult_t ge = ncclGroupEnd();
     if (nr == ncclSuccess) nr = ge;
     hipError_t e = hipSuccess;
-    if (nr == ncclSuccess && c->rank == root && total > 0)
+    if (nr == ncclSuccess && c->rank == root && total > 0 && out)  // out == NULL: the rows are only wanted on the device
         e = hipMemcpyAsync(out, d_all.ptr, (size_t)total * row_bytes, hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = e2;
     staged.release();
-    d_all.release();
+    if (nr == ncclSuccess && e == hipSuccess && c->rank == root && row_bytes == 60) c->gathered_n = total;
     if (nr != ncclSuccess) return fail(WFA_E_RCCL, "row gather failed: %s", ncclGetErrorString(nr));
     if (e != hipSuccess) return fail(WFA_E_HIP, "row gather failed: %s", hipGetErrorString(e));
     return WFA_OK;

@@ -427,6 +427,33 @@ class DeviceSession:
                                                         _ptr(out["t_min"]), _ptr(out["t_max"])))
         return out
 
+    # ---- the same stages on device-resident THRESHOLD_HIT_DTYPE rows (no host columns in, none needed out) ------------
+    def hit_rows_source(self, which: str = "hits") -> None:
+        """Rows the *_resident stages read: "hits" = the last hit pass of this session, "gather" = the rows the last
+        rccl_gather_rows left on the root."""
+        _lib.check(self._lib.wfa_hit_rows_source(self._h, {"hits": 1, "gather": 2}[which]))
+
+    def group_hit_windows_resident(self, n: int, time_window_ns: float) -> dict:
+        """group_hit_windows on the n resident rows (sample window = edge_start / edge_end, as for hit_threshold rows)."""
+        m = C.c_int64(0)
+        _lib.check(self._lib.wfa_group_hit_windows_count(self._h, int(n), *([None] * 10), float(time_window_ns), C.byref(m)))
+        k = int(m.value)
+        out = {"order": np.empty(n, np.int64), "event_start": np.empty(k + 1, np.int64),
+               "t_min": np.empty(k, np.int64), "t_max": np.empty(k, np.int64)}
+        _lib.check(self._lib.wfa_group_hit_windows_fill(self._h, int(n), k, _ptr(out["order"]), _ptr(out["event_start"]),
+                                                        _ptr(out["t_min"]), _ptr(out["t_max"])))
+        return out
+
+    def hit_merge_clusters_resident(self, n: int, merge_gap_ns: float, max_total_width_ns: float):
+        """hit_merge_clusters on the n resident rows: (order, cluster_offset)."""
+        m = C.c_int64(0)
+        _lib.check(self._lib.wfa_hit_merge_count(self._h, int(n), *([None] * 7), float(merge_gap_ns),
+                                                 float(max_total_width_ns), C.byref(m)))
+        order = np.empty(n, np.int64)
+        offset = np.empty(int(m.value) + 1, np.int64)
+        _lib.check(self._lib.wfa_hit_merge_fill(self._h, int(n), int(m.value), _ptr(order), _ptr(offset)))
+        return order, offset
+
     def basic_features(self, source: int = _lib.SRC_RAW, height_range=(40, 90), area_range=(0, None),
                        fixed_baseline: np.ndarray | None = None) -> np.ndarray:
         out = np.zeros(self.n_records, dtype=BASIC_FEATURES_DTYPE)
@@ -449,6 +476,16 @@ class DeviceSession:
 
     def sync(self) -> None:
         _lib.check(self._lib.wfa_sync(self._h))
+
+    def last_h2d_rate(self) -> float:
+        """GB/s of the last large upload through the pinned staging ring."""
+        v = C.c_double(0.0)
+        _lib.check(self._lib.wfa_last_h2d_rate(self._h, C.byref(v)))
+        return float(v.value)
+
+    def set_option(self, name: str, value: bool = True) -> None:
+        """Select between code paths with identical results (wfa_set_option: tests and measurement only)."""
+        _lib.check(self._lib.wfa_set_option(self._h, name.encode(), int(bool(value))))
 
     # -- measurement ----------------------------------------------------------------------------
     def profile(self, on: bool = True) -> None:
@@ -477,13 +514,15 @@ class DeviceSession:
         _lib.check(self._lib.wfa_rccl_init(self._h, int(rank), int(n_ranks), buf))
         self.rank, self.n_ranks = int(rank), int(n_ranks)
 
-    def rccl_gather_rows(self, rows: np.ndarray | None, n_rows: int, row_dtype: np.dtype, root: int = 0):
+    def rccl_gather_rows(self, rows: np.ndarray | None, n_rows: int, row_dtype: np.dtype, root: int = 0,
+                         download: bool = True):
         """Gather structured rows from all ranks to `root` (rank order).  rows=None sends the
-        device-resident hit rows of the last hit pass.  Returns (counts, rows-or-None)."""
+        device-resident hit rows of the last hit pass.  Returns (counts, rows-or-None).  download=False leaves the
+        gathered rows on the root's device only (hit_rows_source("gather") + the *_resident stages read them)."""
         row_dtype = np.dtype(row_dtype)
         counts = np.zeros(self.n_ranks, dtype=np.int64)
         _lib.check(self._lib.wfa_rccl_allgather_counts(self._h, int(n_rows), _ptr(counts)))
-        out = np.empty(int(counts.sum()), dtype=row_dtype) if self.rank == root else None
+        out = np.empty(int(counts.sum()), dtype=row_dtype) if (self.rank == root and download) else None
         src = None if rows is None else np.ascontiguousarray(rows)
         _lib.check(self._lib.wfa_rccl_gather_rows(self._h, _ptr(src), int(n_rows), row_dtype.itemsize,
                                                   int(root), _ptr(counts), _ptr(out)))

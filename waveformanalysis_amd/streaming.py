@@ -314,38 +314,77 @@ class HipThresholdHitStream(HipStreamingPlugin):
         self.max_len = int(max_len)   # padded width of the whole run (hit_finder.py:364), 0 = per chunk
         self.device_pool = device_pool
 
-    def compute_chunk(self, chunk: Chunk, context: Any, run_id: str, **_kw) -> Chunk:
-        wave_pool = context.get_data(run_id, "wave_pool")
+    def _empty(self, chunk: Chunk, run_id: str) -> Chunk:
+        return Chunk(np.zeros(0, dtype=THRESHOLD_HIT_DTYPE), chunk.start, chunk.end, run_id, self.provides,
+                     data_kind="hits", time_field="timestamp")
+
+    def _stage(self, sess, chunk: Chunk, wave_pool: np.ndarray) -> None:
+        """Upload the chunk's samples + records and queue its hit pass on `sess` (returns without waiting for the kernels
+        once the session has sized its row buffers: wfa_hits_enqueue)."""
         recs = chunk.data
-        if len(recs) == 0:
-            return Chunk(np.zeros(0, dtype=THRESHOLD_HIT_DTYPE), chunk.start, chunk.end, run_id, self.provides,
-                         data_kind="hits", time_field="timestamp")
         # the chunk's samples are one contiguous slice of the pool for time-sorted records
         lo = int(recs["wave_offset"].min())
         hi = int((recs["wave_offset"].astype(np.int64) + recs["event_length"]).max())
         sub = recs.copy()
         sub["wave_offset"] -= lo
-        # worker threads come and go with every compute(): the session is borrowed for this chunk only
-        with self._pool(context).borrow() as sess:
-            sess.upload_pool(np.ascontiguousarray(wave_pool[lo:hi]))
-            sess.upload_records(sub, self.threshold)
-            if self.use_filtered:
-                sess.set_sg_plan(*self.sg)
-                hits = sess.threshold_hits(_lib.SRC_SG_FUSED, self.le, self.re, self.max_len)
-            else:
-                hits = sess.threshold_hits(_lib.SRC_RAW, self.le, self.re, self.max_len)
+        sess.upload_pool(np.ascontiguousarray(wave_pool[lo:hi]))   # pinned staging ring: chunk by chunk onto the wire
+        sess.upload_records(sub, self.threshold)
+        if self.use_filtered:
+            sess.set_sg_plan(*self.sg)
+        sess.hits_enqueue(_lib.SRC_SG_FUSED if self.use_filtered else _lib.SRC_RAW, (0, 0), self.le, self.re, self.max_len)
+
+    def _collect(self, sess, chunk: Chunk, run_id: str) -> Chunk:
+        hits = sess._fill_hits(sess.hits_wait())
         # a record that overlaps the chunk's end (non-strict halo selection) has hits behind it: the result chunk
         # spans every record it was computed from; the driver clips it back to the core range
-        end = max(int(chunk.end), int(self._endtime_of(recs, "timestamp").max()) + 1)
+        end = max(int(chunk.end), int(self._endtime_of(chunk.data, "timestamp").max()) + 1)
         return Chunk(hits, chunk.start, end, run_id, self.provides, data_kind="hits", time_field="timestamp",
                      metadata=dict(chunk.metadata))
 
-    def run_chunks(self, chunks: list[Chunk], context: Any, run_id: str, max_workers: int = 4) -> list[Chunk]:
-        """Ordered results, chunks processed concurrently (one session / HIP stream per worker)."""
+    def compute_chunk(self, chunk: Chunk, context: Any, run_id: str, **_kw) -> Chunk:
+        if len(chunk.data) == 0:
+            return self._empty(chunk, run_id)
+        wave_pool = context.get_data(run_id, "wave_pool")
+        # worker threads come and go with every compute(): the session is borrowed for this chunk only
+        with self._pool(context).borrow() as sess:
+            self._stage(sess, chunk, wave_pool)
+            return self._collect(sess, chunk, run_id)
+
+    def run_chunks(self, chunks: list[Chunk], context: Any, run_id: str, max_workers: int = 4,
+                   timeline: list | None = None) -> list[Chunk]:
+        """Ordered results.  One host thread drives two sessions (two HIP streams, two device pools) as a double
+        buffer: while the kernels of chunk k run on one session, chunk k + 1 is uploaded through the other session's
+        pinned staging ring; nobody waits for chunk k before chunk k + 1 is queued.  `timeline` (optional) receives
+        (k, t_stage_begin, t_queued, t_collected) host times per chunk."""
         if not self.parallel or max_workers <= 1 or len(chunks) <= 1:
             return [self.compute_chunk(c, context, run_id) for c in chunks]
-        with ThreadPoolExecutor(max_workers=max_workers) as ex:
-            return list(ex.map(lambda c: self.compute_chunk(c, context, run_id), chunks))
+        import time
+
+        wave_pool = context.get_data(run_id, "wave_pool")
+        out: list[Chunk | None] = [None] * len(chunks)
+        pool = self._pool(context)
+        with pool.borrow() as s0, pool.borrow() as s1:
+            pending = None  # (k, session, stamps) of the chunk whose kernels are running
+            for k, chunk in enumerate(chunks):
+                if len(chunk.data) == 0:
+                    out[k] = self._empty(chunk, run_id)
+                    continue
+                sess = s1 if pending is not None and pending[1] is s0 else s0
+                t0 = time.perf_counter()
+                self._stage(sess, chunk, wave_pool)
+                t1 = time.perf_counter()
+                if pending is not None:
+                    pk, ps, stamps = pending
+                    out[pk] = self._collect(ps, chunks[pk], run_id)
+                    if timeline is not None:
+                        timeline.append((pk, *stamps, time.perf_counter()))
+                pending = (k, sess, (t0, t1))
+            if pending is not None:
+                pk, ps, stamps = pending
+                out[pk] = self._collect(ps, chunks[pk], run_id)
+                if timeline is not None:
+                    timeline.append((pk, *stamps, time.perf_counter()))
+        return out
 
 
 __all__ = ["Chunk", "records_to_chunks", "HipStreamingPlugin", "HipThresholdHitStream"]
