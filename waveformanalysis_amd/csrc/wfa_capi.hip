@@ -663,7 +663,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                         &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows,
-                      &c->gathered, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
+                      &c->gathered, &c->pw_plan, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
                       &c->shadow_pool, &c->shadow_off};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ht) b.release();
@@ -810,6 +810,7 @@ int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int3
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->R = R;
     c->max_len = max_len;
+    c->pw_plan_n = -1;
     c->no_runs32 = false;
     c->have_records = true;
     c->n_hits = -1;
@@ -1165,9 +1166,15 @@ int wfa_basic_features(wfa_ctx* c, int source, int64_t h0, int64_t h1, int h_has
     if ((rc = c->out_rows.ensure((size_t)c->R * 36))) return rc;
     {
         LaunchTimer t(c);
-        WFA_HIP_CHECK(launch_basic_features(c->stream, source, pool_view(c), rec_view(c), sg_params(c), fp,
-                                            c->out_rows.as<uint8_t>()));
-        if ((rc = t.end("k_basic_features"))) return rc;
+        hipError_t e = hipSuccess;
+        if (source == WFA_SRC_RAW && launch_basic_features_wave(c, rec_view(c), fp, c->out_rows.as<uint8_t>(), &e)) {
+            WFA_HIP_CHECK(e);
+            if ((rc = t.end("k_basic_features_wave"))) return rc;
+        } else {
+            WFA_HIP_CHECK(launch_basic_features(c->stream, source, pool_view(c), rec_view(c), sg_params(c), fp,
+                                                c->out_rows.as<uint8_t>()));
+            if ((rc = t.end("k_basic_features"))) return rc;
+        }
     }
     WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 36, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1281,9 +1288,15 @@ int wfa_width_integral(wfa_ctx* c, int source, double q_low, double q_high, doub
     if (rc2) return rc2;
     {
         LaunchTimer t(c);
-        WFA_HIP_CHECK(launch_width_integral(c->stream, source, pool_view(c), rec_view(c), sg_params(c), wp,
-                                            c->out_rows.as<uint8_t>()));
-        if ((rc = t.end("k_width_integral"))) return rc;
+        hipError_t e = hipSuccess;
+        if (source == WFA_SRC_RAW && launch_width_integral_wave(c, rec_view(c), wp, c->out_rows.as<uint8_t>(), &e)) {
+            WFA_HIP_CHECK(e);
+            if ((rc = t.end("k_width_integral_wave"))) return rc;
+        } else {
+            WFA_HIP_CHECK(launch_width_integral(c->stream, source, pool_view(c), rec_view(c), sg_params(c), wp,
+                                                c->out_rows.as<uint8_t>()));
+            if ((rc = t.end("k_width_integral"))) return rc;
+        }
     }
     WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 52, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));

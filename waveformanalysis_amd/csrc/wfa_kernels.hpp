@@ -215,6 +215,14 @@ hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecV
 hipError_t launch_hit_rows_literal(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                    const SgParams& sg, const RowParams& rp, const int4* desc, int64_t n_hits,
                                    bool only_flagged, uint8_t* out);
+struct FeatParams;
+struct WidthParams;
+}  // namespace wfa
+struct wfa_ctx;
+namespace wfa {
+// uniform records: wave-per-record kernels (wfa_features.hip); false = layout not covered, launch the general kernel
+bool launch_basic_features_wave(wfa_ctx* c, const RecView& rec, const FeatParams& fp, uint8_t* out, hipError_t* err);
+bool launch_width_integral_wave(wfa_ctx* c, const RecView& rec, const WidthParams& wp, uint8_t* out, hipError_t* err);
 hipError_t launch_basic_features(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const FeatParams& fp, uint8_t* out);
 hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
