@@ -131,6 +131,7 @@ struct wfa_ctx {
     wfa::DevBuf out_rows;  // per-record feature rows
     wfa::DevBuf pw_plan;   // numpy pairwise-sum plan of the wave-per-record feature kernels (wfa_features.hip)
     int pw_plan_n = -1;    // reduction length the device copy was built for
+    wfa::DevBuf fw_ties;   // width-integral records whose quantile positions are re-walked in numpy's order
     wfa::DevBuf peak_out;  // HIT_DTYPE rows of the last find_peaks pass
     int64_t n_peaks = -1;
     int64_t n_legacy = -1;  // hits of the last wfa_find_hits_count pass

@@ -32,7 +32,9 @@ namespace wfa {
 struct PwPlan {
     int16_t a[64], len[64];
     int8_t partner[8][64];  // level l: value[slot] += value[partner[l][slot]] (or -1)
-    int32_t n_leaf, n_level, n, max_len, min_len, pad[3];
+    int32_t n_leaf, n_level, n, max_len, min_len;
+    int32_t dpp_tree;  // the leaves pair up as a balanced binary tree of <= 16 leaves: lane butterflies combine them
+    int32_t pad[2];
 };
 
 static int pw_build(PwPlan& p, int a, int n, int& depth_out) {
@@ -67,14 +69,23 @@ static bool pw_plan(PwPlan& p, int n) {
     int d = 0;
     pw_build(p, 0, n, d);
     if (p.min_len < 8) p.min_len = 0;  // a single short leaf: sequential
-    return p.n_leaf <= 64 && p.n_level <= 8;
+    if (p.n_leaf > 64 || p.n_level > 8) return false;
+    p.dpp_tree = p.n_leaf <= 16 && (p.n_leaf & (p.n_leaf - 1)) == 0 && (1 << p.n_level) == p.n_leaf;
+    for (int lv = 0; lv < p.n_level && p.dpp_tree; ++lv)
+        for (int k = 0; k < p.n_leaf; ++k) {
+            const int want = (k % (2 << lv)) == 0 ? k + (1 << lv) : -1;
+            if (p.partner[lv][k] != want) { p.dpp_tree = 0; break; }
+        }
+    return true;
 }
 
 namespace {
 
-constexpr int kFwBlock = 256;
+constexpr int kFwBlock = 64;   // one wave: LDS (one staged group per wave) is what limits the waves per CU
+constexpr int kFwWaves = kFwBlock / kWave;
 constexpr int kFwMaxChunks = 16;   // 16-byte chunks per lane: staged group (<= 8192 samples per wave), leaf (<= 128 samples)
 constexpr int kFwGroupSamples = 8192;
+constexpr int kFwCUs = 256;  // MI355X
 
 typedef unsigned short fw_us2 __attribute__((ext_vector_type(2)));
 typedef uint32_t fw_u4 __attribute__((ext_vector_type(4)));
@@ -87,6 +98,7 @@ struct FwParams {
     int32_t gl_shift;        // lanes per record = 1 << gl_shift; records per wave = 64 >> gl_shift
     const double* fixed_bl;
     double q_low, q_high, dt;
+    int32_t* ties;  // [0] = count, then the records whose quantile positions numpy's own order has to decide
 };
 
 // the three ways the reference forms a sample's term (basic_features.py:150-175, waveform_width_integral.py:180-190)
@@ -106,12 +118,11 @@ struct TermMixed {  // records of both kinds in one wave
 };
 
 template <bool CLIP, class F>
-__device__ __forceinline__ void chunk_terms(const uint4& v, const F& f, double (&t)[8]) {
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+__device__ __forceinline__ void chunk_terms(const fw_u4& v, const F& f, double (&t)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        t[2 * i] = f(d[i] & 0xffffu);
-        t[2 * i + 1] = f(d[i] >> 16);
+        t[2 * i] = f(v[i] & 0xffffu);
+        t[2 * i + 1] = f(v[i] >> 16);
     }
     if (CLIP) {
 #pragma unroll
@@ -121,24 +132,41 @@ __device__ __forceinline__ void chunk_terms(const uint4& v, const F& f, double (
 
 // One leaf of numpy's pairwise_sum per lane: q = the leaf's first chunk in LDS, len its length.  Returns the leaf's sum;
 // with CUM also the running (sequential) sum after each chunk, cs[m], the partial tail counted as one more chunk.
+// cmin / cmax: the chunk counts of the shortest / longest leaf of the plan (wave-uniform): chunks below cmin are read four
+// at a time without a per-lane test, so their LDS reads are in flight together (a lane without a leaf reads leaf 0 and
+// its result is dropped by the caller).
 template <bool CLIP, bool CUM, class F>
-__device__ __forceinline__ double leaf_sum_lane(const uint4* q, int len, const F& f, double (&cs)[kFwMaxChunks + 1]) {
+__device__ __forceinline__ double leaf_sum_lane(const fw_u4* q, int len, int cmin, int cmax, const F& f,
+                                                double (&cs)[kFwMaxChunks + 1]) {
     const int cnt = len >> 3, nt = len & 7;
     double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double tot = 0.0;
+    auto take = [&](int m, const fw_u4& v) __attribute__((always_inline)) {
+        double t[8];
+        chunk_terms<CLIP>(v, f, t);
 #pragma unroll
-    for (int m = 0; m < kFwMaxChunks; ++m) {
-        if (m < cnt) {
-            double t[8];
-            chunk_terms<CLIP>(q[m], f, t);
+        for (int j = 0; j < 8; ++j) r[j] = m == 0 ? t[j] : r[j] + t[j];  // r[j] = a[j]; r[j] += a[i + j]
+        if (CUM) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = m == 0 ? t[j] : r[j] + t[j];  // r[j] = a[j]; r[j] += a[i + j]
-            if (CUM) {
+            for (int j = 0; j < 8; ++j) tot += t[j];
+        }
+    };
+    constexpr int B = CUM ? 4 : 1;  // chunks read together (registers: the basic-features kernel runs at 3 waves per SIMD)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tot += t[j];
+    for (int mb = 0; mb < kFwMaxChunks; mb += B) {
+        if (mb + B <= cmin) {
+            fw_u4 v[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) v[i] = q[mb + i];
+#pragma unroll
+            for (int i = 0; i < B; ++i) { take(mb + i, v[i]); if (CUM) cs[mb + i] = tot; }
+        } else {
+#pragma unroll
+            for (int m = mb; m < mb + B; ++m) {
+                if (m < cmax && m < cnt) take(m, q[m]);
+                if (CUM) cs[m] = tot;
             }
         }
-        if (CUM) cs[m] = tot;
     }
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     if (cnt == 0) res = 0.0;  // n < 8: res = 0.; res += a[i]
@@ -153,64 +181,106 @@ __device__ __forceinline__ double leaf_sum_lane(const uint4* q, int len, const F
     return res;
 }
 
-// first sample of this lane's leaf at which the cumulative sum reaches `t` (INT32_MAX: not in this leaf).  excl = the
-// cumulative value in front of the leaf.  near = the decision was closer than `tol` (the order of the additions could
-// change it).
+// First samples of this lane's leaf at which the cumulative sum reaches t[0] and t[1] (INT32_MAX: not in this leaf).
+// excl = the cumulative value in front of the leaf.  near[i] = the decision was closer than tol[i] (the order of the
+// additions could change it).
 template <class F>
-__device__ __forceinline__ int leaf_crossing(const uint4* q, int a, int len, const F& f, const double (&cs)[kFwMaxChunks + 1],
-                                             double excl, double t, double tol, bool& near) {
+__device__ __forceinline__ void leaf_crossings(const fw_u4* q, int a, int len, const F& f, const double (&cs)[kFwMaxChunks + 1],
+                                               double excl, const double (&t)[2], const double (&tol)[2], int (&found)[2],
+                                               bool (&near)[2]) {
     const int cnt = len >> 3, nt = len & 7, nch = cnt + (nt ? 1 : 0);
-    int mm = 0;
-    double start = 0.0;
+    int mm[2] = {0, 0};
+    double start[2] = {0.0, 0.0};
 #pragma unroll
-    for (int m = 0; m < kFwMaxChunks; ++m) {  // cs is non-decreasing: the chunks in front of the crossing
-        const bool below = m < cnt && excl + cs[m] < t;
-        mm += below ? 1 : 0;
-        start = below ? cs[m] : start;
-    }
-    if (nt && mm == cnt && excl + cs[kFwMaxChunks] < t) { mm = cnt + 1; start = cs[kFwMaxChunks]; }  // the partial chunk
-    near = false;
-    if (mm >= nch) {  // not in this leaf; its last value may still be too close to the target to call
-        near = nch > 0 && t - (excl + start) <= tol;
-        return INT32_MAX;
-    }
-    double tv[8];
-    chunk_terms<true>(q[mm], f, tv);
-    const int valid = mm < cnt ? 8 : nt;
-    double run = excl + start;
-    int found = INT32_MAX;
+    for (int m = 0; m < kFwMaxChunks; ++m) {  // cs is non-decreasing: the chunks in front of each crossing
+        const double e = excl + cs[m];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const double before = run;
-        run += tv[j];
-        if (j < valid && found == INT32_MAX && run >= t) {
-            found = a + mm * 8 + j;
-            near = run - t <= tol || t - before <= tol;
+        for (int i = 0; i < 2; ++i) {
+            const bool below = m < cnt && e < t[i];
+            mm[i] += below ? 1 : 0;
+            start[i] = below ? cs[m] : start[i];
         }
     }
-    if (found == INT32_MAX) near = t - run <= tol;  // ended just below the target
-    return found;
+    const double e_end = excl + cs[kFwMaxChunks];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (nt && mm[i] == cnt && e_end < t[i]) { mm[i] = cnt + 1; start[i] = cs[kFwMaxChunks]; }  // the partial chunk
+        found[i] = INT32_MAX;
+        near[i] = false;
+        if (mm[i] >= nch) {  // not in this leaf; its last value may still be too close to the target to call
+            near[i] = nch > 0 && t[i] - (excl + start[i]) <= tol[i];
+            mm[i] = -1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (mm[i] >= 0) {
+            double tv[8];
+            chunk_terms<true>(q[mm[i]], f, tv);
+            const int valid = mm[i] < cnt ? 8 : nt;
+            double run = excl + start[i];
+            bool open = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double before = run;
+                run = j < valid ? run + tv[j] : run;
+                if (j < valid && open && run >= t[i]) {
+                    open = false;
+                    found[i] = a + mm[i] * 8 + j;
+                    near[i] = run - t[i] <= tol[i] || t[i] - before <= tol[i];
+                }
+            }
+            if (open) near[i] = t[i] - run <= tol[i];  // ended just below the target
+        }
+    }
 }
 
+// min / max over the aligned group of gl (power of two) lanes; every lane gets the result.  Steps inside a row of 16
+// lanes are DPP moves (no LDS round trip): quad swaps, then mirrors, which pair lanes that already agree per quad / half.
 __device__ __forceinline__ int group_min_i32(int v, int gl) {
-    for (int m = 1; m < gl; m <<= 1) { const int o = __shfl_xor(v, m, kWave); v = o < v ? o : v; }
+    int o;
+    if (gl > 1) { o = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = o < v ? o : v; }
+    if (gl > 2) { o = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = o < v ? o : v; }
+    if (gl > 4) { o = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = o < v ? o : v; }  // row_half_mirror
+    if (gl > 8) { o = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false); v = o < v ? o : v; }  // row_mirror
+    for (int m = 16; m < gl; m <<= 1) { o = __shfl_xor(v, m, kWave); v = o < v ? o : v; }
     return v;
 }
-__device__ __forceinline__ int group_max_i32(int v, int gl) {
-    for (int m = 1; m < gl; m <<= 1) { const int o = __shfl_xor(v, m, kWave); v = o > v ? o : v; }
-    return v;
+__device__ __forceinline__ int group_max_i32(int v, int gl) { return ~group_min_i32(~v, gl); }
+
+// double across lanes with DPP: sel 0/1/2 as dpp_f64, 3 = row_mirror
+__device__ __forceinline__ double fw_dpp_f64(double v, int sel) {
+    if (sel < 3) return dpp_f64(v, sel);
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(uint32_t)(uint64_t)b, hi = (int)(uint32_t)((uint64_t)b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+// the value D lanes below in the same row of 16 lanes (0.0 where there is none)
+template <int D>
+__device__ __forceinline__ double fw_row_shr_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(uint32_t)(uint64_t)b, hi = (int)(uint32_t)((uint64_t)b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + D, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
 }
 
-struct FwMeta {  // per-record columns, fetched one group ahead together with the samples
-    double baseline;
+struct FwMeta {  // per-record columns as loaded, fetched one group ahead together with the samples (nothing here may
+    double bl, fb;  // be computed on before the next group's turn: that would wait for the whole prefetch)
+    int32_t pol;
+};
+struct FwCold {  // columns that are only copied into the row: loaded at the end of a group's turn, stored with its row
     int64_t ts;
-    int32_t pol, bc;
+    uint32_t board, chan;
 };
 
 // MODE 0: BASIC_FEATURES_DTYPE rows (36 B); MODE 1: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B).
 // A wave takes a group of 64 >> gl_shift consecutive records; lane = (record of the group, leaf of the reduction).
-template <int MODE>
-__global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
+// PFN: 16-byte chunks a lane stages per group (13 covers 8 records of up to 832 samples).
+template <int MODE, int PFN>
+__global__ __launch_bounds__(kFwBlock, MODE == 0 ? 3 : 2) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
                                                             uint8_t* __restrict__ out) {
     __shared__ PwPlan plan;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -228,14 +298,14 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
     uint16_t* smp = reinterpret_cast<uint16_t*>(s_dyn + (size_t)wv * per_wave);
     double* leaf_sum = reinterpret_cast<double*>(s_dyn + (size_t)wv * per_wave + (size_t)RW * L * 2 + 16);
     const int64_t n_groups = (rec.R + RW - 1) / RW;
-    const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + wv;
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t wave0 = (int64_t)blockIdx.x * kFwWaves + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * kFwWaves;
     const fw_u4* __restrict__ p16 = reinterpret_cast<const fw_u4*>(fw.pool) + (fw.off0 >> 3);
 
     const bool leaf_live = k < plan.n_leaf;
     const int la = leaf_live ? plan.a[k] : 0, llen = leaf_live ? plan.len[k] : 0;
 
-    fw_u4 pf[kFwMaxChunks];
+    fw_u4 pf[PFN];
     FwMeta nx;
     auto fetch = [&](int64_t grp) __attribute__((always_inline)) {
         const int64_t r0 = grp * RW;
@@ -243,43 +313,76 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
         const int chunks = nrec * CH;
         const fw_u4* src = p16 + r0 * CH;
 #pragma unroll
-        for (int t = 0; t < kFwMaxChunks; ++t) {
+        for (int t = 0; t < PFN; ++t) {
             const int c = t * kWave + lane;
             pf[t] = src[c < chunks ? c : 0];  // unconditional: the loads of a group issue back to back
         }
-        nx.baseline = 0.0; nx.ts = 0; nx.pol = 0; nx.bc = 0;
-        if (g < nrec) {
-            const int64_t r = r0 + g;
-            nx.baseline = rec.baseline[r];
-            if (MODE == 0 && fw.fixed_bl) {
-                const double fb = fw.fixed_bl[r];
-                if (fb == fb) nx.baseline = fb;  // basic_features.py:143-146
-            }
-            nx.pol = rec.pol[r];
-            nx.ts = rec.ts[r];
-            nx.bc = (int32_t)((uint32_t)(uint16_t)rec.board[r] | ((uint32_t)(uint16_t)rec.chan[r] << 16));
+        const int64_t r = g < nrec ? r0 + g : r0;  // a lane past the end repeats the group's first record (never written)
+        nx.bl = rec.baseline[r];
+        nx.fb = (MODE == 0 && fw.fixed_bl) ? fw.fixed_bl[r] : 0.0;
+        nx.pol = rec.pol[r];
+    };
+
+    // A row is stored one group late, in front of the next prefetch: vmcnt counts loads and stores in order, so a store
+    // issued after the prefetch would make the wait for the prefetched samples wait for the store's round trip too.
+    constexpr int kRowDw = MODE == 0 ? 9 : 13, kRowKeep = MODE == 0 ? 4 : 8;  // dwords computed here: 4 floats / 6 floats + q
+    uint32_t prow[kRowKeep];
+    FwCold cold;
+    auto flush_row = [&](int64_t done) __attribute__((always_inline)) {  // the rows of group `done`, formed one turn ago
+        const int64_t r = done * RW + g;
+        if (k == 0 && r < rec.R) {
+            uint32_t* at = reinterpret_cast<uint32_t*>(out + r * (kRowDw * 4));
+#pragma unroll
+            for (int i = 0; i < kRowKeep; ++i) at[i] = prow[i];
+            put_i64(at, kRowKeep, cold.ts);
+            at[kRowKeep + 2] = cold.board | (cold.chan << 16);
+            put_i64(at, kRowKeep + 3, r);
+        }
+    };
+    auto fetch_cold = [&](int64_t r) __attribute__((always_inline)) {
+        if (k == 0 && r < rec.R) {
+            cold.ts = rec.ts[r];
+            cold.board = (uint16_t)rec.board[r];
+            cold.chan = (uint16_t)rec.chan[r];
         }
     };
 
+#ifdef WFA_FW_TIMING
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tit = 0;
+#define FW_T(i) do { const long long t_now = (long long)__builtin_readcyclecounter(); tph[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define FW_T(i) do { } while (0)
+#endif
     int64_t grp = uniform_i64(wave0);
     if (grp < n_groups) fetch(grp);
+#ifdef WFA_FW_TIMING
+    long long t_last = (long long)__builtin_readcyclecounter();
+#endif
     for (; grp < n_groups; grp += nwaves) {
         const int64_t r0 = grp * RW;
         const int nrec = (int)(rec.R - r0 < RW ? rec.R - r0 : RW);
         const int chunks = nrec * CH;
 #pragma unroll
-        for (int t = 0; t < kFwMaxChunks; ++t) {
+        for (int t = 0; t < PFN; ++t) {
             const int c = t * kWave + lane;
             if (c < chunks) reinterpret_cast<fw_u4*>(smp)[c] = pf[t];
         }
         const FwMeta me = nx;
+        FW_T(0);  // wait for the prefetch + LDS writes
+        if (grp != wave0) flush_row(grp - nwaves);
         if (grp + nwaves < n_groups) fetch(grp + nwaves);  // in flight while this group is reduced
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        FW_T(1);  // row store + prefetch issue
+#ifdef WFA_FW_NOCOMPUTE
+        if (fw.L > 0) { prow[0] = smp[lane]; continue; }
+#endif
 
         const bool valid = g < nrec;
         const int64_t r = r0 + g;
         const int pol = me.pol;
-        const double baseline = me.baseline;
+        double baseline = me.bl;
+        if (MODE == 0 && fw.fixed_bl && me.fb == me.fb) baseline = me.fb;  // basic_features.py:143-146
         const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
         const bool wpos = pol == WFA_POL_POSITIVE_WAVE;
         const float b32 = (float)baseline;
@@ -287,56 +390,90 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
         const TermWave tw{wpos ? 1.0 : -1.0, wpos ? -baseline : baseline};
         const bool all_known = __ballot(valid && !known) == 0, all_wave = __ballot(valid && known) == 0;
         const uint16_t* mine = smp + g * L;
-        const uint4* q = reinterpret_cast<const uint4*>(mine + fw.c0 + la);  // c0 % 8 == 0, la % 8 == 0
+        const fw_u4* q = reinterpret_cast<const fw_u4*>(mine + fw.c0 + la);  // c0 % 8 == 0, la % 8 == 0
+        const int cmin = plan.min_len >> 3, cmax = (plan.max_len + 7) >> 3;
         double cs[kFwMaxChunks + 1];
         double res;
         constexpr bool W = MODE == 1;
-        if (all_known) res = leaf_sum_lane<W, W>(q, llen, tk, cs);
-        else if (all_wave) res = leaf_sum_lane<W, W>(q, llen, tw, cs);
-        else res = leaf_sum_lane<W, W>(q, llen, TermMixed{tk, tw, known}, cs);
+        if (all_known) res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, tk, cs);
+        else if (all_wave) res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, tw, cs);
+        else res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, TermMixed{tk, tw, known}, cs);
+        if (W && !leaf_live) {
+#pragma unroll
+            for (int m = 0; m <= kFwMaxChunks; ++m) cs[m] = 0.0;
+        }
+        FW_T(2);  // leaf sums
         // the leaves of a record combine along numpy's recursion tree
         double* ls = leaf_sum + g * GL;
-        if (leaf_live) ls[k] = res;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int lv = 0; lv < plan.n_level; ++lv) {
-            const int p = leaf_live ? plan.partner[lv][k] : -1;
-            double v = 0.0;
-            if (p >= 0) v = ls[k] + ls[p];
+        double root;
+        if (plan.dpp_tree) {  // balanced: level l pairs the lanes 2^l apart (a + b == b + a bit for bit)
+            root = res;
+            if (plan.n_level > 0) root += fw_dpp_f64(root, 0);
+            if (plan.n_level > 1) root += fw_dpp_f64(root, 1);
+            if (plan.n_level > 2) root += fw_dpp_f64(root, 2);
+            if (plan.n_level > 3) root += fw_dpp_f64(root, 3);
+            if (GL != plan.n_leaf) root = __shfl(root, 0, GL);  // lanes without a leaf need it too
+        } else {
+            if (leaf_live) ls[k] = res;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (p >= 0) ls[k] = v;
+            for (int lv = 0; lv < plan.n_level; ++lv) {
+                const int p = leaf_live ? plan.partner[lv][k] : -1;
+                double v = 0.0;
+                if (p >= 0) v = ls[k] + ls[p];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (p >= 0) ls[k] = v;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            root = plan.n_leaf > 0 ? ls[0] : 0.0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        const double total = 0.0 + (plan.n_leaf > 0 ? ls[0] : 0.0);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const double total = 0.0 + (plan.n_leaf > 0 ? root : 0.0);
+        FW_T(3);  // tree
 
         if (MODE == 0) {
-            // min / max of the raw samples over the height range: the record's lanes stride over it
+            // min / max of the raw samples over the height range: the record's lanes stride over it, four reads in flight
             int wmin = INT32_MAX, wmax = INT32_MIN;
-            for (int i = fw.p0 + k; i < fw.p1; i += GL) {
-                const int x = mine[i];
-                wmin = x < wmin ? x : wmin;
-                wmax = x > wmax ? x : wmax;
+            {
+                const int span = fw.p1 - fw.p0;
+                const int n_it = span > 0 ? (span + GL - 1) >> fw.gl_shift : 0;  // wave-uniform
+                for (int it = 0; it < n_it; it += 4) {
+                    int x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = fw.p0 + k + ((it + u) << fw.gl_shift);
+                        x[u] = mine[i < fw.p1 ? i : fw.p0];  // a repeat of the first sample changes neither extreme
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        wmin = x[u] < wmin ? x[u] : wmin;
+                        wmax = x[u] > wmax ? x[u] : wmax;
+                    }
+                }
             }
-            // max |difference| over the record: each lane a run of chunks, two samples per operation
+            // max |difference| over the record: each lane a run of chunks, two samples per operation.  Every lane reads
+            // the same number of chunks (the last lane of a record repeats its last one, masked), so the reads batch.
             const int cpl = (CH + GL - 1) >> fw.gl_shift;
             const int cb = k * cpl, ce = cb + cpl < CH ? cb + cpl : CH;
-            const uint4* rc = reinterpret_cast<const uint4*>(mine);
+            const fw_u4* rc = reinterpret_cast<const fw_u4*>(mine);
             fw_us2 dacc = {0, 0};
-            uint32_t prev = 0;
-            if (cb < ce) prev = cb > 0 ? reinterpret_cast<const uint32_t*>(mine)[cb * 4 - 1] : (uint32_t)mine[0] << 16;
+            uint32_t prev = cb > 0 && cb < CH ? reinterpret_cast<const uint32_t*>(mine)[cb * 4 - 1] : (uint32_t)mine[0] << 16;
 #pragma unroll
             for (int t = 0; t < kFwMaxChunks; ++t) {
-                if (cb + t < ce) {
-                    const uint4 v = rc[cb + t];
-                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                if (t < cpl) {  // wave-uniform
+                    const int c = cb + t < CH ? cb + t : CH - 1;
+                    const fw_u4 v = rc[c];
+                    fw_us2 cacc = {0, 0};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const uint32_t sh = __builtin_amdgcn_alignbit(d[i], prev, 16);  // the same samples, one place earlier
-                        const fw_us2 cur = __builtin_bit_cast(fw_us2, d[i]), old = __builtin_bit_cast(fw_us2, sh);
+                        const uint32_t di = v[i];  // (a bit_cast straight from the vector element reads element 0)
+                        const uint32_t sh = __builtin_amdgcn_alignbit(di, prev, 16);  // the same samples, one place earlier
+                        const fw_us2 cur = __builtin_bit_cast(fw_us2, di), old = __builtin_bit_cast(fw_us2, sh);
                         const fw_us2 df = __builtin_elementwise_max(cur, old) - __builtin_elementwise_min(cur, old);
-                        dacc = __builtin_elementwise_max(dacc, df);
-                        prev = d[i];
+                        cacc = __builtin_elementwise_max(cacc, df);
+                        prev = di;
                     }
+                    const uint32_t keep = cb + t < ce ? __builtin_bit_cast(uint32_t, cacc) : 0u;
+                    dacc = __builtin_elementwise_max(dacc, __builtin_bit_cast(fw_us2, keep));
                 }
             }
             int dmax = dacc.x > dacc.y ? dacc.x : dacc.y;
@@ -344,7 +481,7 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
             wmax = group_max_i32(wmax, GL);
             dmax = group_max_i32(dmax, GL);
             if (valid && k == 0) {
-                uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 36);
+                uint32_t* row = prow;
                 float height = 0.f, amp = 0.f, area_f = 0.f, mad_f = 0.f;
                 if (fw.p1 > fw.p0) {
                     double vmin, vmax;  // of `val` as the reference forms it (monotone in the sample)
@@ -365,9 +502,6 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
                 put_f32(row, 1, amp);
                 put_f32(row, 2, area_f);
                 put_f32(row, 3, mad_f);
-                put_i64(row, 4, me.ts);
-                row[6] = (uint32_t)me.bc;
-                put_i64(row, 7, r);
             }
         } else {
             // quantile positions of x_i = max(signal_i, 0) (waveform_width_integral.py:180-231).  np.cumsum is sequential:
@@ -377,52 +511,52 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
             const bool ok = qsum > 0.0 && qsum <= 1.7976931348623157e308;  // finite and positive
             const double t_lo = fw.q_low * qsum, t_hi = fw.q_high * qsum;
             double incl = cs[kFwMaxChunks];
-            for (int d = 1; d < GL; d <<= 1) {
-                const double o = __shfl_up(incl, d, GL);
-                if (k >= d) incl += o;
-            }
-            double excl = __shfl_up(incl, 1, GL);
-            if (k == 0) excl = 0.0;
-            const double last = __shfl(incl, GL - 1, GL);
-            const double eps = 8.0 * (double)L * 1.1102230246251565e-16;
-            bool n_lo = false, n_hi = false;
-            int f_lo, f_hi;
-            if (all_known) {
-                f_lo = leaf_crossing(q, la, llen, tk, cs, excl, t_lo, eps * t_lo, n_lo);
-                f_hi = leaf_crossing(q, la, llen, tk, cs, excl, t_hi, eps * t_hi, n_hi);
-            } else if (all_wave) {
-                f_lo = leaf_crossing(q, la, llen, tw, cs, excl, t_lo, eps * t_lo, n_lo);
-                f_hi = leaf_crossing(q, la, llen, tw, cs, excl, t_hi, eps * t_hi, n_hi);
+            double excl;
+            if (GL <= 16) {  // a record's lanes sit in one row of 16: DPP shifts, no LDS round trips
+                double o;
+                if (GL > 1) { o = fw_row_shr_f64<1>(incl); if (k >= 1) incl += o; }
+                if (GL > 2) { o = fw_row_shr_f64<2>(incl); if (k >= 2) incl += o; }
+                if (GL > 4) { o = fw_row_shr_f64<4>(incl); if (k >= 4) incl += o; }
+                if (GL > 8) { o = fw_row_shr_f64<8>(incl); if (k >= 8) incl += o; }
+                excl = fw_row_shr_f64<1>(incl);
             } else {
-                const TermMixed tm{tk, tw, known};
-                f_lo = leaf_crossing(q, la, llen, tm, cs, excl, t_lo, eps * t_lo, n_lo);
-                f_hi = leaf_crossing(q, la, llen, tm, cs, excl, t_hi, eps * t_hi, n_hi);
+                for (int d = 1; d < GL; d <<= 1) {
+                    const double o = __shfl_up(incl, d, GL);
+                    if (k >= d) incl += o;
+                }
+                excl = __shfl_up(incl, 1, GL);
             }
-            if (!leaf_live) { f_lo = INT32_MAX; f_hi = INT32_MAX; n_lo = false; n_hi = false; }
+            if (k == 0) excl = 0.0;
+            FW_T(5);  // scan
+            const double eps = 8.0 * (double)L * 1.1102230246251565e-16;
+            const double tt[2] = {t_lo, t_hi}, tol[2] = {eps * t_lo, eps * t_hi};
+            int fnd[2];
+            bool nr[2];
+            if (all_known) leaf_crossings(q, la, llen, tk, cs, excl, tt, tol, fnd, nr);
+            else if (all_wave) leaf_crossings(q, la, llen, tw, cs, excl, tt, tol, fnd, nr);
+            else leaf_crossings(q, la, llen, TermMixed{tk, tw, known}, cs, excl, tt, tol, fnd, nr);
+            FW_T(6);  // crossings
+            if (!leaf_live) { fnd[0] = INT32_MAX; fnd[1] = INT32_MAX; nr[0] = false; nr[1] = false; }
+            const int f_lo = fnd[0], f_hi = fnd[1];
             const int g_lo = group_min_i32(f_lo, GL), g_hi = group_min_i32(f_hi, GL);
             // lanes at or in front of the record's first crossing saw values around the target; the ones behind it did not
-            bool amb = (n_lo && (f_lo == g_lo || f_lo == INT32_MAX)) || (n_hi && (f_hi == g_hi || f_hi == INT32_MAX));
-            amb = amb || (g_lo == INT32_MAX && t_lo - last <= eps * t_lo) || (g_hi == INT32_MAX && t_hi - last <= eps * t_hi);
+            bool amb = (nr[0] && (f_lo == g_lo || f_lo == INT32_MAX)) || (nr[1] && (f_hi == g_hi || f_hi == INT32_MAX));
+            if (__ballot(g_lo == INT32_MAX || g_hi == INT32_MAX)) {  // no crossing at all: the last cumulative value decides
+                const double last = __shfl(incl, GL - 1, GL);
+                amb = amb || (g_lo == INT32_MAX && t_lo - last <= eps * t_lo) || (g_hi == INT32_MAX && t_hi - last <= eps * t_hi);
+            }
             int amb_i = amb ? 1 : 0;
             amb_i = group_max_i32(amb_i, GL);
             int lo_i = g_lo == INT32_MAX ? L : g_lo;  // np.searchsorted returns len(cumsum)
             int hi_i = g_hi == INT32_MAX ? L : g_hi;
-            if (amb_i && ok && valid && k == 0) {  // numpy's own order decides (one lane, sequential)
-                lo_i = -1; hi_i = -1;
-                double c = 0.0;
-                for (int i = 0; i < L && hi_i < 0; ++i) {
-                    const uint32_t x = mine[i];
-                    const double sgl = known ? tk(x) : tw(x);
-                    c += sgl > 0.0 ? sgl : 0.0;
-                    if (lo_i < 0 && c >= t_lo) lo_i = i;
-                    if (hi_i < 0 && c >= t_hi) hi_i = i;
-                }
-                if (lo_i < 0) lo_i = L;
-                if (hi_i < 0) hi_i = L;
+            FW_T(7);  // reductions
+            if (amb_i && ok && valid && k == 0) {  // numpy's own order decides: k_width_ties re-walks the record
+                const int slot = atomicAdd(fw.ties, 1);
+                fw.ties[1 + slot] = (int32_t)r;
             }
             if (!ok) { lo_i = 0; hi_i = 0; }
             if (valid && k == 0) {
-                uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 52);
+                uint32_t* row = prow;
                 const double lo = (double)lo_i, hi = (double)hi_i;
                 const double w = (double)(hi_i - lo_i > 0 ? hi_i - lo_i : 0);
                 put_f32(row, 0, (float)(lo * fw.dt));
@@ -432,12 +566,65 @@ __global__ __launch_bounds__(kFwBlock) void k_features_leaf(FwParams fw, RecView
                 put_f32(row, 4, (float)hi);
                 put_f32(row, 5, (float)w);
                 put_f64(row, 6, qsum);
-                put_i64(row, 8, me.ts);
-                row[10] = (uint32_t)me.bc;
-                put_i64(row, 11, r);
             }
         }
+        fetch_cold(r);  // behind the prefetch in the queue, which the next turn waits for anyway
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        FW_T(4);  // the rest
+#ifdef WFA_FW_TIMING
+        ++tit;
+#endif
+    }
+    if (grp != wave0) flush_row(grp - nwaves);
+#ifdef WFA_FW_TIMING
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 1500))
+        printf("fw mode %d block %d iters %d fallbacks %d cycles/iter: wait+ldsw %lld issue %lld leaf %lld tree %lld rest %lld (scan %lld cross %lld red %lld)\n",
+               MODE, (int)blockIdx.x, tit & 0xffff, tit >> 16, tph[0] / (tit & 0xffff), tph[1] / (tit & 0xffff), tph[2] / (tit & 0xffff),
+               tph[3] / (tit & 0xffff), tph[4] / (tit & 0xffff), tph[5] / (tit & 0xffff), tph[6] / (tit & 0xffff), tph[7] / (tit & 0xffff));
+#endif
+}
+
+// The records k_features_leaf<1> could not call: one lane walks a record in numpy's order (np.cumsum is sequential) and
+// rewrites the six position fields of its row.  A few per thousand records (cumulative values that tie with a target).
+__global__ __launch_bounds__(64) void k_width_ties(FwParams fw, RecView rec, uint8_t* __restrict__ out) {
+    const int n = fw.ties[0];
+    const int CH = fw.L >> 3;
+    const fw_u4* __restrict__ p16 = reinterpret_cast<const fw_u4*>(fw.pool) + (fw.off0 >> 3);
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) {
+        const int64_t r = fw.ties[1 + i];
+        uint32_t* row = reinterpret_cast<uint32_t*>(out + r * 52);
+        const double qsum = __longlong_as_double((long long)((uint64_t)row[6] | ((uint64_t)row[7] << 32)));
+        const double t_lo = fw.q_low * qsum, t_hi = fw.q_high * qsum;
+        const int pol = rec.pol[r];
+        const double baseline = rec.baseline[r];
+        const bool known = pol == WFA_POL_NEGATIVE || pol == WFA_POL_POSITIVE;
+        const bool wpos = pol == WFA_POL_POSITIVE_WAVE;
+        const TermKnown tk{(float)baseline, pol == WFA_POL_POSITIVE ? 0u : 0x80000000u};
+        const TermWave tw{wpos ? 1.0 : -1.0, wpos ? -baseline : baseline};
+        const fw_u4* src = p16 + r * CH;
+        int lo_i = -1, hi_i = -1;
+        double c = 0.0;
+        for (int ch = 0; ch < CH && hi_i < 0; ++ch) {
+            const fw_u4 v = src[ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t x = (j & 1) ? v[j >> 1] >> 16 : v[j >> 1] & 0xffffu;
+                const double sgl = known ? tk(x) : tw(x);
+                c += sgl > 0.0 ? sgl : 0.0;
+                if (lo_i < 0 && c >= t_lo) lo_i = ch * 8 + j;
+                if (hi_i < 0 && c >= t_hi) hi_i = ch * 8 + j;
+            }
+        }
+        if (lo_i < 0) lo_i = fw.L;
+        if (hi_i < 0) hi_i = fw.L;
+        const double lo = (double)lo_i, hi = (double)hi_i;
+        const double w = (double)(hi_i - lo_i > 0 ? hi_i - lo_i : 0);
+        put_f32(row, 0, (float)(lo * fw.dt));
+        put_f32(row, 1, (float)(hi * fw.dt));
+        put_f32(row, 2, (float)(w * fw.dt));
+        put_f32(row, 3, (float)lo);
+        put_f32(row, 4, (float)hi);
+        put_f32(row, 5, (float)w);
     }
 }
 
@@ -461,18 +648,34 @@ static bool features_wave(wfa_ctx* c, int mode, const RecView& rec, FwParams fw,
     fw.pool = c->pool_u16.as<uint16_t>();
     fw.off0 = c->span_off0;
     fw.L = c->span_L;
+    if (mode == 1) {
+        if (rec.R >= INT32_MAX || c->fw_ties.ensure(((size_t)rec.R + 1) * sizeof(int32_t)) != WFA_OK) return false;
+        fw.ties = c->fw_ties.as<int32_t>();
+        *err = hipMemsetAsync(fw.ties, 0, sizeof(int32_t), c->stream);
+        if (*err != hipSuccess) return true;
+    }
     int sh = 0;
     while ((1 << sh) < plan.n_leaf) ++sh;                               // a lane per leaf
     while (sh < 6 && (int64_t)(kWave >> sh) * fw.L > kFwGroupSamples) ++sh;  // <= 8192 samples staged per wave
     fw.gl_shift = sh;
     const int RW = kWave >> sh;
-    const size_t lds = (size_t)kWavesPerBlock * ((size_t)RW * fw.L * 2 + 16 + kWave * 8);
+    const size_t lds = (size_t)kFwWaves * ((size_t)RW * fw.L * 2 + 16 + kWave * 8);
     const int64_t n_groups = (rec.R + RW - 1) / RW;
-    int64_t g = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g > 256 * 4) g = 256 * 4;
+    // persistent waves (each prefetches its next group): exactly the blocks that are resident together
+    const bool small = (int64_t)RW * (fw.L >> 3) <= 13 * kWave;
+    const void* fn = mode == 0 ? (small ? reinterpret_cast<const void*>(k_features_leaf<0, 13>) : reinterpret_cast<const void*>(k_features_leaf<0, 16>))
+                               : (small ? reinterpret_cast<const void*>(k_features_leaf<1, 13>) : reinterpret_cast<const void*>(k_features_leaf<1, 16>));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFwBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    int64_t g = (n_groups + kFwWaves - 1) / kFwWaves;
+    if (g > (int64_t)kFwCUs * per_cu) g = (int64_t)kFwCUs * per_cu;
     const PwPlan* dplan = c->pw_plan.as<PwPlan>();
-    if (mode == 0) hipLaunchKernelGGL((k_features_leaf<0>), dim3((unsigned)g), dim3(kFwBlock), lds, c->stream, fw, rec, dplan, out);
-    else hipLaunchKernelGGL((k_features_leaf<1>), dim3((unsigned)g), dim3(kFwBlock), lds, c->stream, fw, rec, dplan, out);
+    const dim3 grid((unsigned)g), block(kFwBlock);
+    if (mode == 0 && small) hipLaunchKernelGGL((k_features_leaf<0, 13>), grid, block, lds, c->stream, fw, rec, dplan, out);
+    else if (mode == 0) hipLaunchKernelGGL((k_features_leaf<0, 16>), grid, block, lds, c->stream, fw, rec, dplan, out);
+    else if (small) hipLaunchKernelGGL((k_features_leaf<1, 13>), grid, block, lds, c->stream, fw, rec, dplan, out);
+    else hipLaunchKernelGGL((k_features_leaf<1, 16>), grid, block, lds, c->stream, fw, rec, dplan, out);
+    if (mode == 1 && hipGetLastError() == hipSuccess) hipLaunchKernelGGL(k_width_ties, dim3(256), dim3(64), 0, c->stream, fw, rec, out);
     *err = hipGetLastError();
     return true;
 }
