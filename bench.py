@@ -307,8 +307,8 @@ def rank_main(args: argparse.Namespace) -> int:
         # BASELINE config 3: records -> hits -> BasicFeatures(area, width) on the 1e9-sample chunk
         pass_ms = sum(v[0] / max(v[1], 1) for v in prof_all.values())
         c3 = {"hits_pass_ms": round(pass_ms, 4),
-              "k_basic_features_ms": extra_ms.get("k_basic_features_wave", extra_ms.get("k_basic_features")),
-              "k_width_integral_ms": extra_ms.get("k_width_integral_wave", extra_ms.get("k_width_integral"))}
+              "k_basic_features_ms": extra_ms.get("k_basic_features_leaf", extra_ms.get("k_basic_features")),
+              "k_width_integral_ms": extra_ms.get("k_width_integral_leaf", extra_ms.get("k_width_integral"))}
         if c3["k_basic_features_ms"] is not None and c3["k_width_integral_ms"] is not None:
             c3["total_ms"] = round(pass_ms + c3["k_basic_features_ms"] + c3["k_width_integral_ms"], 4)
             c3["Gsamples_per_s"] = round(n_samples / c3["total_ms"] / 1e6, 1)

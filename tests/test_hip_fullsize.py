@@ -87,3 +87,46 @@ def test_full_chunk_properties(chunk):
     k = 20_000
     want = O.threshold_hits_chunked(rec[:k], O.filter_wave_pool_uniform(pool[: k * 800], 800))
     G.assert_struct_equal(rows[rid < k], want, float_rtol=1e-6, what="prefix vs oracle")
+
+
+def test_full_chunk_features(chunk):
+    """Basic features and width/integral rows over all 1e9 samples (the records branch of the C3 plugins).
+
+    * two kernel families: the lane-per-leaf kernels on the uniform layout and the general lane-per-record kernels
+      (`no_span`) walk the same additions in numpy's order by different routes -- byte-identical rows;
+    * restriction: the rows of a prefix uploaded alone (other group and grid shapes, a ragged last group) are the
+      first rows of the full result;
+    * the oracle on a prefix it finishes in seconds, bit for bit;
+    * every quantile position lies inside its record and low <= high.
+    """
+    rec, _rec_in, pool = chunk
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.upload_records(rec, 10.0)
+        sess.profile(True)
+        bf = sess.basic_features(_lib.SRC_RAW, (40, 90), (0, None))
+        wi = sess.width_integral(_lib.SRC_RAW, 0.1, 0.9, 2.0)
+        names = set(sess.profile_report())
+        assert {"k_basic_features_leaf", "k_width_integral_leaf"} <= names, names   # the fast kernels ran
+        np.testing.assert_array_equal(bf["event_index"], np.arange(N_RECORDS))
+        np.testing.assert_array_equal(bf["timestamp"], rec["timestamp"])
+        np.testing.assert_array_equal(wi["timestamp"], rec["timestamp"])
+        lo, hi = wi["t_low_samples"], wi["t_high_samples"]
+        assert np.all((lo >= 0) & (hi <= 800) & (lo <= hi))
+        assert np.all(bf["max_abs_diff"] >= 0) and np.all(np.isfinite(bf["area"]))
+
+        sess.set_option("no_span", True)                              # the general kernels
+        bf_general = sess.basic_features(_lib.SRC_RAW, (40, 90), (0, None))
+        wi_general = sess.width_integral(_lib.SRC_RAW, 0.1, 0.9, 2.0)
+        sess.set_option("no_span", False)
+        assert bf_general.tobytes() == bf.tobytes()
+        assert wi_general.tobytes() == wi.tobytes()
+
+        k = 200_003                                                    # not a multiple of the 8-record group
+        sess.upload_records(rec[:k], 10.0)
+        assert sess.basic_features(_lib.SRC_RAW, (40, 90), (0, None)).tobytes() == bf[:k].tobytes()
+        assert sess.width_integral(_lib.SRC_RAW, 0.1, 0.9, 2.0).tobytes() == wi[:k].tobytes()
+
+    k = 20_000
+    G.assert_struct_equal(bf[:k], O.basic_features(rec[:k], pool[: k * 800]), what="basic features prefix vs oracle (bit-exact)")
+    G.assert_struct_equal(wi[:k], O.width_integral(rec[:k], pool[: k * 800], dt=2.0), what="width integral prefix vs oracle (bit-exact)")

@@ -1169,7 +1169,7 @@ int wfa_basic_features(wfa_ctx* c, int source, int64_t h0, int64_t h1, int h_has
         hipError_t e = hipSuccess;
         if (source == WFA_SRC_RAW && launch_basic_features_wave(c, rec_view(c), fp, c->out_rows.as<uint8_t>(), &e)) {
             WFA_HIP_CHECK(e);
-            if ((rc = t.end("k_basic_features_wave"))) return rc;
+            if ((rc = t.end("k_basic_features_leaf"))) return rc;
         } else {
             WFA_HIP_CHECK(launch_basic_features(c->stream, source, pool_view(c), rec_view(c), sg_params(c), fp,
                                                 c->out_rows.as<uint8_t>()));
@@ -1291,7 +1291,7 @@ int wfa_width_integral(wfa_ctx* c, int source, double q_low, double q_high, doub
         hipError_t e = hipSuccess;
         if (source == WFA_SRC_RAW && launch_width_integral_wave(c, rec_view(c), wp, c->out_rows.as<uint8_t>(), &e)) {
             WFA_HIP_CHECK(e);
-            if ((rc = t.end("k_width_integral_wave"))) return rc;
+            if ((rc = t.end("k_width_integral_leaf"))) return rc;
         } else {
             WFA_HIP_CHECK(launch_width_integral(c->stream, source, pool_view(c), rec_view(c), sg_params(c), wp,
                                                 c->out_rows.as<uint8_t>()));

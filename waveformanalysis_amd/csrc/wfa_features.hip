@@ -1,24 +1,26 @@
-// Per-record features on uniform records, one WAVE per record (BasicFeaturesPlugin records branch,
-// cpu/basic_features.py:108-195; WaveformWidthIntegralPlugin, cpu/waveform_width_integral.py:83-231).
+// Per-record features on uniform records (BasicFeaturesPlugin records branch, cpu/basic_features.py:108-195;
+// WaveformWidthIntegralPlugin, cpu/waveform_width_integral.py:83-231).
 //
 // The reference reduces with numpy, whose float64 results depend on the order of the additions; the rows must be bit
 // identical.  The general kernels (wfa_kernels.hip: k_basic_features / k_width_integral) give every lane a whole record
 // and walk it in numpy's order: correct for any layout, but a lane-per-record walk reads 16 bytes at a 1600-byte stride
-// and runs 800 dependent float64 additions (0.12-0.15 of the HBM roofline).  Here the record is staged in LDS with
-// coalesced 16-byte loads and numpy's order is mapped onto the wave:
+// and runs 800 dependent float64 additions (0.12-0.15 of the HBM roofline).  Here numpy's order is mapped onto lanes:
 //   np.sum  = pairwise_sum (umath/loops_utils.h.src): halves split at multiples of 8 down to leaves of <= 128 elements,
 //             a leaf = 8 interleaved accumulators r_j = sum over m of x[a + 8 m + j], combined as
 //             ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then its n % 8 tail added sequentially.
-//             lane = (leaf, accumulator): 8 leaves x 8 accumulators per pass (an 800-sample record has exactly 8 leaves:
-//             96 + 104 four times); every lane runs its own 12-13 additions in numpy's order, the 8 lanes of a leaf
-//             combine with a DPP butterfly in numpy's parenthesisation, and the leaves combine along the recursion tree,
-//             level by level, from a host-built plan (PwPlan).  Same additions, same operands, same order: bit exact.
-//   min / max / max|diff| are order independent and exact on the raw integers.
-//   np.cumsum + np.searchsorted: strictly sequential in numpy.  A wave scan adds in a different order, so its values may
-//             differ from numpy's in the last bits; the quantile INDEX differs only if a cumulative value lies within
-//             that rounding distance of the target.  The kernel takes the scan, checks the two values either side of
-//             each crossing against the bound 8 L 2^-53 |target|, and re-walks the record sequentially in the (never
-//             observed) case that one is closer.
+//             LANE = LEAF: an 800-sample record has exactly 8 leaves (96 + 104, four times), so a wave takes a group of
+//             8 consecutive records, stages their 12.8 KB in LDS with coalesced 16-byte loads (the next group's loads
+//             are in flight in registers meanwhile), and every lane walks its leaf 16 bytes at a time with the 8
+//             accumulators in registers: the same additions on the same operands in the same order, 8 independent
+//             chains per lane.  The leaves of a record then combine along numpy's recursion tree from a host-built plan
+//             (PwPlan): lane butterflies when the tree is balanced, through LDS otherwise.
+//   min / max / max|diff| are order independent and exact on the raw integers (two samples per packed operation).
+//   np.cumsum + np.searchsorted: strictly sequential in numpy.  Each lane keeps the sequential sums of its own leaf
+//             (one value per 8 samples), a scan over the record's lanes places them, and the crossing is located inside
+//             one chunk.  Sums formed in another order may differ from numpy's in the last bits, so the INDEX is only
+//             accepted when no value around the crossing lies within 8 L 2^-53 |target| of the target; the other records
+//             (a few per thousand on integer data with a 1/40 baseline: exact ties are common) go to a list that
+//             k_width_ties re-walks, one lane per record, in numpy's order.
 #include <cstring>
 #include <vector>
 
@@ -151,7 +153,7 @@ __device__ __forceinline__ double leaf_sum_lane(const fw_u4* q, int len, int cmi
             for (int j = 0; j < 8; ++j) tot += t[j];
         }
     };
-    constexpr int B = CUM ? 4 : 1;  // chunks read together (registers: the basic-features kernel runs at 3 waves per SIMD)
+    constexpr int B = 4;  // chunks read together (registers: the basic-features kernel runs at 3 waves per SIMD)
 #pragma unroll
     for (int mb = 0; mb < kFwMaxChunks; mb += B) {
         if (mb + B <= cmin) {
@@ -280,7 +282,7 @@ struct FwCold {  // columns that are only copied into the row: loaded at the end
 // A wave takes a group of 64 >> gl_shift consecutive records; lane = (record of the group, leaf of the reduction).
 // PFN: 16-byte chunks a lane stages per group (13 covers 8 records of up to 832 samples).
 template <int MODE, int PFN>
-__global__ __launch_bounds__(kFwBlock, MODE == 0 ? 3 : 2) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
+__global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
                                                             uint8_t* __restrict__ out) {
     __shared__ PwPlan plan;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(kFwBlock, MODE == 0 ? 3 : 2) void k_features_leaf(F
 #pragma unroll
         for (int t = 0; t < PFN; ++t) {
             const int c = t * kWave + lane;
-            pf[t] = src[c < chunks ? c : 0];  // unconditional: the loads of a group issue back to back
+            if ((t + 1) * kWave <= chunks) pf[t] = src[c];  // wave-uniform test
+            else pf[t] = src[c < chunks ? c : 0];           // unconditional all the same: the loads issue back to back
         }
         const int64_t r = g < nrec ? r0 + g : r0;  // a lane past the end repeats the group's first record (never written)
         nx.bl = rec.baseline[r];
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kFwBlock, MODE == 0 ? 3 : 2) void k_features_leaf(F
 #pragma unroll
         for (int t = 0; t < PFN; ++t) {
             const int c = t * kWave + lane;
-            if (c < chunks) reinterpret_cast<fw_u4*>(smp)[c] = pf[t];
+            if ((t + 1) * kWave <= chunks || c < chunks) reinterpret_cast<fw_u4*>(smp)[c] = pf[t];
         }
         const FwMeta me = nx;
         FW_T(0);  // wait for the prefetch + LDS writes
