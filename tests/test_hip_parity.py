@@ -242,7 +242,13 @@ def test_streaming_chunks_with_device_pool():
         for use_filtered in (False, True):
             plugin = HipThresholdHitStream(use_filtered=use_filtered, max_len=800, device_pool=dp)
             chunks = records_to_chunks(rec, 700, "run")
-            outs = plugin.run_chunks(chunks, ctx, "run", max_workers=3)
+            timeline = []
+            outs = plugin.run_chunks(chunks, ctx, "run", max_workers=3, timeline=timeline)
+            # double buffer: chunk k + 1 is staged (uploaded and queued) before anybody waits for chunk k, on the
+            # other of the two sessions; results are collected in input order
+            assert [t[0] for t in timeline] == list(range(len(chunks)))
+            for (k, _b, queued, collected), (_k1, begin1, queued1, _c1) in zip(timeline, timeline[1:]):
+                assert queued <= begin1 <= queued1 <= collected, (k, timeline)
             got = np.concatenate([c.data for c in outs])
             want = O.threshold_hits_chunked(rec, O.filter_wave_pool_uniform(pool, 800) if use_filtered else pool)
             G.assert_struct_equal(got, want, float_rtol=FLOAT_RTOL, what=f"stream filtered={use_filtered}")

@@ -93,9 +93,10 @@ def test_in_fresh_interpreter():
     env = dict(os.environ, WFA_REFCTX_INNER="1", PYTHONDONTWRITEBYTECODE="1",
                PYTHONPATH=os.pathsep.join([REF, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]))
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-p", "no:cacheprovider",
-                          "-k", "inside_reference_context or fails_loudly"], env=env, capture_output=True, text=True,
+                          "-k", "inside_reference_context or fails_loudly or streaming_context"], env=env,
+                         capture_output=True, text=True,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
-    assert res.returncode == 0 and "2 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    assert res.returncode == 0 and "3 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
 
 
 def test_hip_plugins_inside_reference_context(ref_env):
@@ -130,6 +131,89 @@ def test_hip_plugins_inside_reference_context(ref_env):
     cdf = cpu.get_data("run", "df")
     for col in ("area", "height", "amp", "max_abs_diff", "timestamp"):
         np.testing.assert_array_equal(cdf[col].to_numpy(), df[col].to_numpy())
+
+
+class OracleStreamSession:
+    """Stand-in for a borrowed DeviceSession on the streaming path (upload, enqueue, wait): answers with the oracle."""
+
+    def upload_pool(self, pool):
+        self.pool = pool
+
+    def upload_records(self, rec, thr=10.0):
+        self.rec, self.thr = rec, thr
+
+    def set_sg_plan(self, w, p):
+        self.sg = (w, p)
+
+    def hits_enqueue(self, source, baseline_range, le, re, max_len=0):
+        from oracle import wfa_oracle as O
+
+        self.rows = O.threshold_hits(self.rec, self.pool, threshold=self.thr, left_extension=le, right_extension=re)
+
+    def hits_wait(self):
+        return len(self.rows)
+
+    def _fill_hits(self, n):
+        assert n == len(self.rows)
+        return self.rows
+
+
+class OraclePool:
+    def __init__(self):
+        self.borrowed = 0
+        self.live = 0
+        self.max_live = 0
+
+    def borrow(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.borrowed += 1
+            self.live += 1
+            self.max_live = max(self.max_live, self.live)
+            try:
+                yield OracleStreamSession()
+            finally:
+                self.live -= 1
+
+        return cm()
+
+
+def test_hit_stream_through_streaming_context(ref_env):
+    """`hit_threshold_stream` pulled through the reference's own StreamingContext (streaming.py:977-1068): the plugin is a
+    reference StreamingPlugin, its chunks are reference Chunks, compute() is the reference's, and the parallel branch
+    lands in the overridden `_compute_parallel` (two borrowed sessions as a double buffer)."""
+    from oracle import wfa_oracle as O
+    from waveform_analysis.core.plugins.core.streaming import StreamingPlugin, get_streaming_context
+    from waveform_analysis.core.processing.chunk import Chunk
+    from waveformanalysis_amd.streaming import HipStreamingPlugin, HipThresholdHitStream
+
+    assert issubclass(HipStreamingPlugin, StreamingPlugin)
+    ctx, rec, pool = _context(ref_env / "stream")
+    dev = OraclePool()
+    plugin = HipThresholdHitStream(device_pool=dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ctx.register(plugin, allow_override=True)
+    ctx.set_config({"threshold": 12.0}, plugin_name="hit_threshold_stream")
+    sctx = get_streaming_context(ctx, "run", chunk_size=16, parallel=True)
+    chunks = list(sctx.get_stream("hit_threshold_stream"))
+    assert len(chunks) == 3 and all(isinstance(c, Chunk) for c in chunks)          # 40 records in chunks of 16
+    assert dev.borrowed == 2 and dev.max_live == 2                                  # the double buffer, not a thread per chunk
+    rows = np.concatenate([c.data for c in chunks])
+    np.testing.assert_array_equal(rows, O.threshold_hits(rec, pool, threshold=12.0))
+    assert all(c.start <= c.data["timestamp"].min() and c.data["timestamp"].max() < c.end for c in chunks if len(c.data))
+
+    # serial branch (parallel=False): one borrowed session per chunk, same rows; a time range clips the stream
+    dev.borrowed = 0
+    serial = list(get_streaming_context(ctx, "run", chunk_size=16, parallel=False).get_stream("hit_threshold_stream"))
+    assert dev.borrowed == 3
+    np.testing.assert_array_equal(np.concatenate([c.data for c in serial]), rows)
+    t_mid = int(rec["timestamp"][20])
+    part = list(sctx.get_stream("hit_threshold_stream", time_range=(0, t_mid)))
+    got = np.concatenate([c.data for c in part]) if part else rows[:0]
+    assert len(got) and np.all(got["timestamp"] < t_mid) and len(got) < len(rows)
 
 
 def test_missing_extension_fails_loudly_inside_context(ref_env, monkeypatch):

@@ -5,9 +5,14 @@ Mirrors the part of the reference's streaming contract a chunk plugin needs
 core/processing/chunk.py:77-206): a `Chunk` carries a time-contiguous slice of a structured array
 with [start, end) bounds in ps; `compute_chunk(chunk, context, run_id)` maps one chunk to one chunk and
 may be called concurrently from worker threads, so it keeps no per-call state on `self`.  Where the
-reference hands chunks to an ExecutorManager thread pool (`_compute_parallel`), `run_chunks` hands
-them to worker threads that each borrow a `DeviceSession` (one HIP stream on one GPU) from a
-`DevicePool`, chunk k -> GPU (k mod n_gpus).
+reference hands chunks to an ExecutorManager thread pool (`_compute_parallel`, streaming.py:740-860), the
+classes here override `_compute_parallel` to hand them to `DeviceSession`s (one HIP stream on one GPU)
+borrowed from a `DevicePool`.
+
+Inside a reference installation `HipStreamingPlugin` IS a subclass of the reference's `StreamingPlugin` and the
+chunks are the reference's `Chunk` objects, so `get_streaming_context(ctx, run).get_stream("hit_threshold_stream")`
+(streaming.py:977-1068) drives it like any of its own streaming plugins; standalone (tests, GPU box) the same
+class sits on the restatement below.
 """
 
 from __future__ import annotations
@@ -33,7 +38,14 @@ from .chunk import (
 )
 from .device import DevicePool, default_pool
 from .dtypes import THRESHOLD_HIT_DTYPE
+from .plugin_api import Option
 from .sg_plan import normalize_window
+
+try:  # inside a reference installation: be a real subclass of its StreamingPlugin, speak its Chunk
+    from waveform_analysis.core.plugins.core.streaming import StreamingPlugin as _RefStreamingPlugin  # type: ignore
+    from waveform_analysis.core.processing.chunk import Chunk  # type: ignore  # noqa: F811
+except Exception:  # standalone: the restatements (same constructor, same fields)
+    _RefStreamingPlugin = None
 
 
 def _pick_time_field(data, preferred: str):
@@ -49,16 +61,16 @@ def _pick_time_field(data, preferred: str):
     return None
 
 
-class HipStreamingPlugin:
+class _StandaloneStreamingPlugin:
     """Chunk-stream driver with the knobs and the chunking rules of the reference's StreamingPlugin
     (core/plugins/core/streaming.py:119-176, 318-360, 380-445, 463-545, 592-691, 882-910):
 
     * a static structured array is cut into segments at time breaks (`break_threshold_ps`), segments into chunks of
       `chunk_size` rows, each chunk widened by the halo and carrying its core range as metadata main_start/main_end;
     * `compute_chunk` results are wrapped, clipped back to the core range (`clip_strict`) and boundary-checked;
-    * `compute()` is a generator that yields the results in input order; chunks run concurrently on worker threads,
-      each borrowing a DeviceSession (one HIP stream on one GPU) from a DevicePool -- where the reference submits to
-      its ExecutorManager -- unless the plugin is stateful (serial, `reset_state()` at every new segment).
+    * `compute()` is a generator that yields the results in input order; parallel runs go through
+      `_compute_parallel` (streaming.py:740-860), serial ones (stateful plugins, `reset_state()` at every new segment)
+      through the loop below.
     """
 
     provides = "stream"
@@ -84,7 +96,6 @@ class HipStreamingPlugin:
     is_stateful: bool = False
     reset_on_break: bool = True
     break_threshold_ps: int = DEFAULT_BREAK_THRESHOLD_PS
-    device_pool = None
 
     # -- to override --------------------------------------------------------------------------------------
     def compute_chunk(self, chunk: Chunk, context: Any, run_id: str, **kwargs):
@@ -194,15 +205,6 @@ class HipStreamingPlugin:
         if not v.is_valid:
             raise ValueError(f"Chunk boundary violation in {self.provides}: {v.errors}")
 
-    def _pool(self, context: Any = None) -> DevicePool:
-        return self.device_pool or getattr(context, "wfa_device_pool", None) or default_pool()
-
-    def _process(self, chunk: Chunk, context: Any, run_id: str, kwargs: dict):
-        result = self._postprocess_result(self.compute_chunk(chunk, context, run_id, **kwargs), chunk)
-        if result is not None:
-            self._validate_chunk(result)
-        return result
-
     # -- driver -------------------------------------------------------------------------------------------
     STREAMING_CONFIG_KEYS = ("chunk_size", "parallel", "executor_type", "max_workers", "parallel_batch_size",
                              "break_threshold_ps", "required_halo_ns", "required_halo_left_ns",
@@ -243,20 +245,54 @@ class HipStreamingPlugin:
                 if result is not None:
                     yield result
             return
-        workers = int(self.max_workers or 4)
+        for result in self._compute_parallel(chunks, context, run_id, **kwargs):
+            if result is not None:
+                yield result
+
+
+class _DevicePoolMixin:
+    """What both bases get on top: results through `_process`, and `_compute_parallel` (streaming.py:740-860) handing
+    chunks to worker threads that each borrow a DeviceSession from a DevicePool -- chunk k on GPU (k mod n_gpus) --
+    where the reference submits to its ExecutorManager.  Results come back in input order; an exception cancels
+    what has not started and is re-raised."""
+
+    device_pool = None
+
+    def _pool(self, context: Any = None) -> DevicePool:
+        return self.device_pool or getattr(context, "wfa_device_pool", None) or default_pool()
+
+    def _process(self, chunk: Chunk, context: Any, run_id: str, kwargs: dict):
+        result = self._postprocess_result(self.compute_chunk(chunk, context, run_id, **kwargs), chunk)
+        if result is not None:
+            self._validate_chunk(result)
+        return result
+
+    def _compute_parallel(self, input_chunks, context: Any, run_id: str, executor_config: dict | None = None, **kwargs):
+        workers = int((executor_config or {}).get("max_workers") or self.max_workers or 4)
         batch = int(self.parallel_batch_size or 2 * workers)
         with ThreadPoolExecutor(max_workers=workers) as ex:
-            pending = []
-            for chunk in chunks:
-                pending.append(ex.submit(self._process, chunk, context, run_id, kwargs))
-                if len(pending) >= batch:
+            pending: list = []
+            try:
+                for chunk in input_chunks:
+                    pending.append(ex.submit(self._process, chunk, context, run_id, kwargs))
+                    if len(pending) >= batch:
+                        result = pending.pop(0).result()
+                        if result is not None:
+                            yield result
+                while pending:
                     result = pending.pop(0).result()
                     if result is not None:
                         yield result
-            for fut in pending:
-                result = fut.result()
-                if result is not None:
-                    yield result
+            finally:
+                for fut in pending:
+                    fut.cancel()
+
+
+class HipStreamingPlugin(_DevicePoolMixin, _RefStreamingPlugin or _StandaloneStreamingPlugin):
+    """Base of the HIP streaming plugins: the reference's StreamingPlugin when that is importable, the restatement above
+    otherwise, with the device pool behind `_compute_parallel`."""
+
+    provides = "stream"
 
 
 def records_to_chunks(records: np.ndarray, chunk_size: int, run_id: str = "") -> list[Chunk]:
@@ -274,19 +310,62 @@ def records_to_chunks(records: np.ndarray, chunk_size: int, run_id: str = "") ->
     return out
 
 
+_UNSET = object()
+
+
 class HipThresholdHitStream(HipStreamingPlugin):
     """compute_chunk() = threshold hits of one chunk of records (fused SG filter optional).
 
-    `compute(context, run_id)` streams over the static `records` array with the base class's chunking (breaks at
-    10^13 ps, 50 000 records per chunk); hits are instantaneous rows (time = `timestamp`), clipped to the chunk's core
-    range like any stream output."""
+    `compute(context, run_id)` streams over the static `records` array (breaks at 10^13 ps, 50 000 records per chunk);
+    hits are instantaneous rows (time = `timestamp`).  Parallel runs (`_compute_parallel`) drive two borrowed sessions as
+    a double buffer: chunk k + 1 goes through the pinned staging ring of one session while the kernels of chunk k run on
+    the other.  Options are read from the Context like those of HipThresholdHitPlugin (hit_finder.py:82-130); a value
+    given to the constructor wins."""
 
     provides = "hit_threshold_stream"
     depends_on = ["records", "wave_pool"]
+    description = "Threshold hits of the records stream, chunk by chunk (HIP, gfx950)."
+    version = "0.11.0+hip1"
     output_dtype = THRESHOLD_HIT_DTYPE
+    save_when = "never"
     chunk_size = 50_000          # reference default (streaming.py:153-176)
     length_field = "event_length"
     output_data_kind = "hits"
+
+    options = {
+        "threshold": Option(default=10.0, type=float, help="hit threshold"),
+        "left_extension": Option(default=2, type=int, help="samples added left of a hit"),
+        "right_extension": Option(default=2, type=int, help="samples added right of a hit"),
+        "use_filtered": Option(default=False, type=bool, help="threshold the Savitzky-Golay filtered waveform (fused)"),
+        "sg_window_size": Option(default=11, type=int, help="Savitzky-Golay window"),
+        "sg_poly_order": Option(default=2, type=int, help="Savitzky-Golay polynomial order"),
+    }
+
+    def __init__(self, threshold=_UNSET, left_extension=_UNSET, right_extension=_UNSET, use_filtered=_UNSET,
+                 sg_window_size=_UNSET, sg_poly_order=_UNSET, max_len: int = 0, device_pool: DevicePool | None = None):
+        super().__init__()
+        given = dict(threshold=threshold, left_extension=left_extension, right_extension=right_extension,
+                     use_filtered=use_filtered, sg_window_size=sg_window_size, sg_poly_order=sg_poly_order)
+        self._given = {k: v for k, v in given.items() if v is not _UNSET}
+        self.max_len = int(max_len)   # padded width of the whole run (hit_finder.py:364), 0 = per chunk
+        self.device_pool = device_pool
+        self._configure(None)
+
+    def _configure(self, context: Any) -> None:
+        """Constructor argument > Context configuration > option default."""
+        def value(name):
+            if name in self._given:
+                return self._given[name]
+            if context is not None and hasattr(context, "get_config"):
+                v = context.get_config(self, name)
+                if v is not None:
+                    return v
+            return self.options[name].default
+
+        self.threshold = float(value("threshold"))
+        self.le, self.re = max(0, int(value("left_extension"))), max(0, int(value("right_extension")))
+        self.use_filtered = bool(value("use_filtered"))
+        self.sg = normalize_window(value("sg_window_size"), value("sg_poly_order"))
 
     def _endtime_of(self, data: np.ndarray, time_field: str) -> np.ndarray:
         # records: timestamp in ps, dt in ns per sample -> the end of a record in ps
@@ -299,20 +378,18 @@ class HipThresholdHitStream(HipStreamingPlugin):
         (no main_start / main_end in the metadata)."""
         if not isinstance(data, np.ndarray) or data.dtype.names is None:
             raise TypeError("hit_threshold_stream chunks the structured `records` array")
-        for seg, _s, _e, seg_id in self._iter_segments(data, "timestamp"):
+        if len(data) == 0:
+            return
+        if self.break_threshold_ps and self.break_threshold_ps > 0:
+            segments = [seg for seg, _info in split_by_breaks(
+                data, break_threshold_ps=self.break_threshold_ps, min_chunk_size=1, time_field="timestamp",
+                endtime_field=self.endtime_field, dt_field=self.dt_field, length_field=self.length_field, dt=self.dt)]
+        else:
+            segments = [data]
+        for seg_id, seg in enumerate(segments):
             for ch in records_to_chunks(seg, self.chunk_size, run_id):
                 ch.metadata["segment_id"] = seg_id
                 yield ch
-
-    def __init__(self, threshold: float = 10.0, left_extension: int = 2, right_extension: int = 2,
-                 use_filtered: bool = False, sg_window_size: int = 11, sg_poly_order: int = 2,
-                 max_len: int = 0, device_pool: DevicePool | None = None):
-        self.threshold = float(threshold)
-        self.le, self.re = max(0, int(left_extension)), max(0, int(right_extension))
-        self.use_filtered = bool(use_filtered)
-        self.sg = normalize_window(sg_window_size, sg_poly_order)
-        self.max_len = int(max_len)   # padded width of the whole run (hit_finder.py:364), 0 = per chunk
-        self.device_pool = device_pool
 
     def _empty(self, chunk: Chunk, run_id: str) -> Chunk:
         return Chunk(np.zeros(0, dtype=THRESHOLD_HIT_DTYPE), chunk.start, chunk.end, run_id, self.provides,
@@ -344,47 +421,64 @@ class HipThresholdHitStream(HipStreamingPlugin):
     def compute_chunk(self, chunk: Chunk, context: Any, run_id: str, **_kw) -> Chunk:
         if len(chunk.data) == 0:
             return self._empty(chunk, run_id)
+        self._configure(context)
         wave_pool = context.get_data(run_id, "wave_pool")
         # worker threads come and go with every compute(): the session is borrowed for this chunk only
         with self._pool(context).borrow() as sess:
             self._stage(sess, chunk, wave_pool)
             return self._collect(sess, chunk, run_id)
 
-    def run_chunks(self, chunks: list[Chunk], context: Any, run_id: str, max_workers: int = 4,
-                   timeline: list | None = None) -> list[Chunk]:
-        """Ordered results.  One host thread drives two sessions (two HIP streams, two device pools) as a double
-        buffer: while the kernels of chunk k run on one session, chunk k + 1 is uploaded through the other session's
-        pinned staging ring; nobody waits for chunk k before chunk k + 1 is queued.  `timeline` (optional) receives
-        (k, t_stage_begin, t_queued, t_collected) host times per chunk."""
-        if not self.parallel or max_workers <= 1 or len(chunks) <= 1:
-            return [self.compute_chunk(c, context, run_id) for c in chunks]
+    def _pipeline(self, input_chunks, context: Any, run_id: str, timeline: list | None = None):
+        """(input chunk, raw result) pairs in input order.  One host thread drives two sessions (two HIP streams, two
+        device pools) as a double buffer: while the kernels of chunk k run on one session, chunk k + 1 is uploaded
+        through the other session's pinned staging ring; nobody waits for chunk k before chunk k + 1 is queued.
+        `timeline` (optional) receives (k, t_stage_begin, t_queued, t_collected) host times per chunk."""
         import time
 
+        self._configure(context)
         wave_pool = context.get_data(run_id, "wave_pool")
-        out: list[Chunk | None] = [None] * len(chunks)
         pool = self._pool(context)
         with pool.borrow() as s0, pool.borrow() as s1:
-            pending = None  # (k, session, stamps) of the chunk whose kernels are running
-            for k, chunk in enumerate(chunks):
+            pending = None  # (k, chunk, session, stamps) of the chunk whose kernels are running
+
+            def finish():
+                pk, pchunk, ps, stamps = pending
+                result = self._collect(ps, pchunk, run_id)
+                if timeline is not None:
+                    timeline.append((pk, *stamps, time.perf_counter()))
+                return pchunk, result
+
+            for k, chunk in enumerate(input_chunks):
                 if len(chunk.data) == 0:
-                    out[k] = self._empty(chunk, run_id)
+                    if pending is not None:
+                        yield finish()
+                        pending = None
+                    yield chunk, self._empty(chunk, run_id)
                     continue
-                sess = s1 if pending is not None and pending[1] is s0 else s0
+                sess = s1 if pending is not None and pending[2] is s0 else s0
                 t0 = time.perf_counter()
                 self._stage(sess, chunk, wave_pool)
                 t1 = time.perf_counter()
                 if pending is not None:
-                    pk, ps, stamps = pending
-                    out[pk] = self._collect(ps, chunks[pk], run_id)
-                    if timeline is not None:
-                        timeline.append((pk, *stamps, time.perf_counter()))
-                pending = (k, sess, (t0, t1))
+                    yield finish()
+                pending = (k, chunk, sess, (t0, t1))
             if pending is not None:
-                pk, ps, stamps = pending
-                out[pk] = self._collect(ps, chunks[pk], run_id)
-                if timeline is not None:
-                    timeline.append((pk, *stamps, time.perf_counter()))
-        return out
+                yield finish()
+
+    def _compute_parallel(self, input_chunks, context: Any, run_id: str, executor_config: dict | None = None, **kwargs):
+        """streaming.py:740-860, with the device pool in the place of the executor."""
+        for chunk, raw in self._pipeline(input_chunks, context, run_id):
+            result = self._postprocess_result(raw, chunk)
+            if result is not None:
+                self._validate_chunk(result)
+                yield result
+
+    def run_chunks(self, chunks: list[Chunk], context: Any, run_id: str, max_workers: int = 4,
+                   timeline: list | None = None) -> list[Chunk]:
+        """The raw results of `chunks`, in order (the bench and the parity tests call this with ready-made chunks)."""
+        if not self.parallel or max_workers <= 1 or len(chunks) <= 1:
+            return [self.compute_chunk(c, context, run_id) for c in chunks]
+        return [raw for _chunk, raw in self._pipeline(chunks, context, run_id, timeline)]
 
 
 __all__ = ["Chunk", "records_to_chunks", "HipStreamingPlugin", "HipThresholdHitStream"]
