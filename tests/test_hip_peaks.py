@@ -81,6 +81,28 @@ def test_against_oracle_medium(sess, cfg):
         G.assert_struct_equal(got, want, what=f"src {src} cfg {cfg}")
 
 
+def test_one_walk_and_two_walk_candidate_paths(sess):
+    """The candidate list comes from one walk into per-record slots (k_find_peaks_slots + k_peak_compact) unless a
+    record has more candidates than slots, then from the count + fill pair; `no_peak_slots` forces the pair.  Same rows."""
+    rec, pool = synth.make_run(4000, "v1725", cfg=34)
+    filt = O.filter_wave_pool_uniform(pool, 800)
+    sess.upload_pool(filt)
+    sess.upload_records(rec, 0.0)
+    for cfg, route in ((dict(), "k_peak_compact"), (dict(height=1.0, prominence=0.1, width=1), "k_find_peaks<fill candidates>")):
+        sess.profile(True)
+        got = sess.find_peaks(_lib.SRC_F32, **cfg)
+        names = set(sess.profile_report())
+        assert "k_find_peaks_slots" in names and route in names, names
+        sess.set_option("no_peak_slots", True)
+        sess.profile(True)
+        two_walks = sess.find_peaks(_lib.SRC_F32, **cfg)
+        assert "k_find_peaks<count candidates>" in set(sess.profile_report())
+        sess.set_option("no_peak_slots", False)
+        assert len(got) > 0 and got.tobytes() == two_walks.tobytes()
+        G.assert_struct_equal(got, O.find_peak_hits(rec, filt, **cfg), what=f"{cfg}")
+    sess.profile(False)
+
+
 def test_edge_cases(sess):
     rec, pool = synth.make_run(8, "v1725", cfg=5)
     # records too short for any peak, and an empty record list

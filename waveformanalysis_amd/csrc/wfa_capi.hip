@@ -659,7 +659,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->pool_u16, &c->pool_f32, &c->off, &c->len, &c->baseline, &c->pol, &c->thr,
                       &c->ts, &c->dt, &c->board, &c->chan, &c->rid, &c->fixed_bl, &c->bm_off, &c->bitmap,
-                      &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
+                      &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val, &c->peak_slot_pos, &c->peak_slot_val,
                         &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows,
@@ -690,6 +690,7 @@ int wfa_set_option(wfa_ctx* c, const char* name, int value) {
     else if (n == "no_pad") c->opt.no_pad = v;
     else if (n == "no_runs32") c->opt.no_runs32 = v;
     else if (n == "no_speculate") c->opt.no_speculate = v;
+    else if (n == "no_peak_slots") c->opt.no_peak_slots = v;
     else return fail(WFA_E_INVALID, "unknown option '%s'", name);
     return WFA_OK;
 }
@@ -1075,11 +1076,25 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int signal_mode, int use_deriva
         int64_t* cand_start = c->rec_tmp_start.as<int64_t>();
         int32_t* cand_n = c->peak_cand_n.as<int32_t>();
         int64_t n_cand = 0;
-        {
+        // one walk: counts + the first kPeakSlots candidates of every record in per-record slots (launch_find_peaks_slots);
+        // `no_peak_slots` keeps the count + fill pair (two walks, any number of candidates)
+        const int K = kPeakSlots;
+        const bool slots = !c->opt.no_peak_slots;
+        int* overflow = err + 1;
+        if (slots) {
+            if ((rc = c->peak_slot_pos.ensure((size_t)R * K * sizeof(int32_t)))) return rc;
+            if ((rc = c->peak_slot_val.ensure((size_t)R * K * sizeof(double)))) return rc;
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_find_peaks_slots(c->stream, source, pv, rv, pp, K, counts, c->peak_slot_pos.as<int32_t>(),
+                                                  c->peak_slot_val.as<double>(), overflow));
+            if ((rc = t.end("k_find_peaks_slots"))) return rc;
+        } else {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_find_peaks(c->stream, source, false, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr));
             if ((rc = t.end("k_find_peaks<count candidates>"))) return rc;
         }
+        int over = 0;
+        WFA_HIP_CHECK(hipMemcpyAsync(&over, overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         if ((rc = scan_total(cand_start, &n_cand))) return rc;
         const size_t nc = (size_t)(n_cand > 0 ? n_cand : 1);
         if ((rc = c->peak_cand_pos.ensure(nc * sizeof(int32_t)))) return rc;
@@ -1094,7 +1109,12 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int signal_mode, int use_deriva
         int64_t* crec = c->peak_cand_rec.as<int64_t>();
         uint8_t* cstate = distance > 2 ? c->peak_cand_state.as<uint8_t>() : nullptr;
         int32_t* accept = c->peak_accept.as<int32_t>();
-        {
+        if (slots && !over) {
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_peak_compact(c->stream, R, K, counts, cand_start, c->peak_slot_pos.as<int32_t>(),
+                                              c->peak_slot_val.as<double>(), cpos, cval, crec));
+            if ((rc = t.end("k_peak_compact"))) return rc;
+        } else {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_find_peaks(c->stream, source, true, pv, rv, pp, nullptr, cand_start, cpos, cval, crec));
             if ((rc = t.end("k_find_peaks<fill candidates>"))) return rc;

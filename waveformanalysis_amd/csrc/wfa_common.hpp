@@ -120,6 +120,7 @@ struct wfa_ctx {
         bool no_pad = false;       // no padded shadow layout
         bool no_runs32 = false;    // bitmap route (k_sg_mask_span16 + scan + k_hit_runs) instead of k_sg_runs32
         bool no_speculate = false; // exact row launches (host round trip for the hit count)
+        bool no_peak_slots = false; // find_peaks: count + fill walks instead of one walk into per-record slots
     } opt;
     wfa::RunsCold* h_cold = nullptr;   // pinned staging (lives behind h_total)
     wfa::RunsCold run_cold_host{};     // what the device copy holds
@@ -136,6 +137,7 @@ struct wfa_ctx {
     int64_t n_peaks = -1;
     int64_t n_legacy = -1;  // hits of the last wfa_find_hits_count pass
     wfa::DevBuf peak_cand_n, peak_cand_pos, peak_cand_val, peak_cand_state;  // candidate lists of find_peaks
+    wfa::DevBuf peak_slot_pos, peak_slot_val;  // kPeakSlots candidates per record, written by the single walk
     wfa::DevBuf peak_cand_rec, peak_accept, peak_ips, peak_row_start;
     wfa::DevBuf wh_pos, wh_row, wh_valid;  // per-hit inputs of k_waveform_width
     // hit-table stages (wfa_hits.hip): scratch slots and the state of the last count pass

@@ -2157,7 +2157,8 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
         }
     };
     // the next chunk is requested before the current one is consumed (two buffers, loop unrolled by two so that no
-    // register copy waits for the load); the chunk behind the record's last one is a valid address (pool slack)
+    // register copy waits for the load); the chunk behind the record's last one is a valid address (pool slack).
+    // (A ring of four, unrolled by four, makes the body large enough that hipcc stops inlining it: 3x slower.)
     float wa[8], wb[8];
     double wd[8];
     load_chunk<SRC>(pool, c_lo, wd, wa);
@@ -2200,6 +2201,49 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecVie
     if (!FILL) counts[r] = n_out;
 }
 
+// One walk instead of count + fill: every record writes its first `K` candidates into its own K slots and its full
+// count; the scan of the counts gives the compact offsets and k_peak_compact moves the slots there.  A record with
+// more than K candidates raises `overflow` and the caller falls back to the fill walk (the counts are exact either way).
+template <int SRC>
+__global__ __launch_bounds__(kPeakBlock) void k_find_peaks_slots(PoolView pool, RecView rec, PeakParams pp, int K,
+                                                                 int32_t* __restrict__ counts,
+                                                                 int32_t* __restrict__ slot_pos,
+                                                                 double* __restrict__ slot_val, int* __restrict__ overflow) {
+    const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    if (r >= rec.R) return;
+    SignalAt<SRC> S;
+    S.bind(pool, rec, r, pp);
+    int n_out = 0;
+    if (S.L > 0) {
+        const int64_t base = r * K;
+        scan_candidates(pool, rec.off[r], S, pp, [&](int peak, double val) {
+            if (n_out < K) {
+                slot_pos[base + n_out] = peak;
+                slot_val[base + n_out] = val;
+            }
+            ++n_out;
+        });
+    }
+    counts[r] = n_out;
+    if (n_out > K) atomicOr(overflow, 1);
+}
+
+__global__ __launch_bounds__(kPeakBlock) void k_peak_compact(int64_t R, int K, const int32_t* __restrict__ counts,
+                                                             const int64_t* __restrict__ cand_start,
+                                                             const int32_t* __restrict__ slot_pos,
+                                                             const double* __restrict__ slot_val,
+                                                             int32_t* __restrict__ cand_pos, double* __restrict__ cand_val,
+                                                             int64_t* __restrict__ cand_rec) {
+    const int64_t t = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
+    const int64_t r = t / K;
+    const int k = (int)(t - r * K);
+    if (r >= R || k >= counts[r]) return;
+    const int64_t dst = cand_start[r] + k;
+    cand_pos[dst] = slot_pos[t];
+    cand_val[dst] = slot_val[t];
+    cand_rec[dst] = r;
+}
+
 // _select_by_peak_distance on the candidate list of each record: visit candidates by descending value (ties: the
 // later candidate first == a stable ascending argsort read backwards) and drop the not-yet-dropped neighbours
 // closer than `distance`.  state: 1 = kept & unvisited, 2 = kept & visited, 0 = dropped.
@@ -2236,6 +2280,8 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_eval(PoolView pool, RecView
                                                           const int32_t* __restrict__ cand_pos,
                                                           const uint8_t* __restrict__ state,
                                                           int32_t* __restrict__ accept, double* __restrict__ ips) {
+    // (Handing the lanes of a wave candidates of similar height -- a radix sort by value in front -- did not pay:
+    // 1.58 ms against 1.21 ms, the walks of neighbouring candidates share cache lines.)
     const int64_t k = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (k >= n_cand) return;
     int ok = 0;
@@ -2507,6 +2553,27 @@ hipError_t launch_find_peaks(hipStream_t st, int source, bool fill, const PoolVi
     if (source == WFA_SRC_RAW) { if (fill) WFA_PK(WFA_SRC_RAW, true); else WFA_PK(WFA_SRC_RAW, false); }
     else { if (fill) WFA_PK(WFA_SRC_F32, true); else WFA_PK(WFA_SRC_F32, false); }
 #undef WFA_PK
+    return hipGetLastError();
+}
+
+hipError_t launch_find_peaks_slots(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                                   int K, int32_t* counts, int32_t* slot_pos, double* slot_val, int* overflow) {
+    if (rec.R == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((rec.R + kPeakBlock - 1) / kPeakBlock);
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_find_peaks_slots<WFA_SRC_RAW>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, K, counts, slot_pos, slot_val, overflow);
+    else
+        hipLaunchKernelGGL((k_find_peaks_slots<WFA_SRC_F32>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, K, counts, slot_pos, slot_val, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_peak_compact(hipStream_t st, int64_t R, int K, const int32_t* counts, const int64_t* cand_start,
+                               const int32_t* slot_pos, const double* slot_val, int32_t* cand_pos, double* cand_val,
+                               int64_t* cand_rec) {
+    if (R == 0) return hipSuccess;
+    const int64_t n = R * K;
+    hipLaunchKernelGGL(k_peak_compact, dim3((unsigned)((n + kPeakBlock - 1) / kPeakBlock)), dim3(kPeakBlock), 0, st, R, K, counts,
+                       cand_start, slot_pos, slot_val, cand_pos, cand_val, cand_rec);
     return hipGetLastError();
 }
 
