@@ -13,7 +13,7 @@ from waveformanalysis_amd.channel_config import per_record_option, scatter_per_r
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_", "legacy_", "chunk_", "v1725bin_", "densehit_", "sigpeaks_", "vx2730csv_")):
+def case_names(prefix_exclude=("grouping_", "peaks_", "dense_", "merge_", "sort_", "legacy_", "chunk_", "v1725bin_", "densehit_", "sigpeaks_", "vx2730csv_", "c5_")):
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
     return [n for n in names if not n.startswith(tuple(prefix_exclude))]
 
