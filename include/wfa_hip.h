@@ -37,7 +37,9 @@ extern "C" {
 #define WFA_E_RCCL (-5)
 #define WFA_E_LIMIT (-6)     /* record longer than WFA_MAX_RECORD_SAMPLES etc. */
 
-#define WFA_MAX_RECORD_SAMPLES 32760
+/* The plain threshold kernel keeps a record's hit bitmap in LDS (one 64-bit word per 64 samples, 4 waves per block,
+ * 64 KiB): 2038 words.  Everything else indexes samples with 32-bit integers and sums them in 64 bits. */
+#define WFA_MAX_RECORD_SAMPLES 130432
 #define WFA_MAX_SG_WINDOW 63
 
 /* wave source of a consumer (reference: cpu/_wave_source.py:119-165, records branch) */

@@ -350,9 +350,9 @@ __global__ __launch_bounds__(kBlock) void k_sg_mask(PoolView pool, RecView rec, 
         double baseline;
         if (FUSED_BASELINE) {
             const int e = mp.bl_end < L ? mp.bl_end : L;
-            int s = 0;
+            int64_t s = 0;
             for (int i = mp.bl_start + lane; i < e; i += kWave) s += src.xu[i];
-            const int tot = wave_sum_i32_dpp(s);  // <= 32760 * 65535 < 2^31
+            const int64_t tot = wave_sum_i64(s);  // exact for any window (WFA_MAX_RECORD_SAMPLES * 65535 < 2^53)
             baseline = (e <= mp.bl_start) ? __longlong_as_double(0x7ff8000000000000LL)
                                           : (double)tot / (double)(e - mp.bl_start);
             if (lane == 0) rec.baseline_rw[r] = baseline;
@@ -1231,12 +1231,20 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
         const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
         // a sample outside the window gets t = +inf: it never wins the extremum and its signal is -inf, clamped to 0
         const int idx0 = ilo + rel0;
+        {
+            // integer guard: the smallest numerator of every chunk a working lane evaluates (the samples of a chunk that
+            // lie outside the window are ordinary neighbours of the same record: at worst a hit goes to the literal
+            // kernel that did not have to)
+            int zm = Z[0] < Z[1] ? Z[0] : Z[1];
+#pragma unroll
+            for (int j = 2; j < 8; ++j) zm = Z[j] < zm ? Z[j] : zm;
+            zm = lane_ok ? zm : INT32_MAX;
+            y_num_min = zm < y_num_min ? zm : y_num_min;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool in = lane_ok && (unsigned)(rel0 + j) < (unsigned)wlen;
             const int y_num = Z[j] + bias_i;
-            const int y_chk = in ? y_num : INT32_MAX;
-            y_num_min = y_chk < y_num_min ? y_chk : y_num_min;
             const float y32 = (float)((double)y_num * sg.rden);
             // (the compiler branches around this block when no lane of the wave has sample j in its window; forcing a
             // straight-line loop measured 0.475 ms against 0.456: short hits leave most of a round's slots empty)
@@ -1261,7 +1269,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
             do_round(c, cur);
         }
     }
-    need_literal |= y_num_min < guard;
+    need_literal |= y_num_min != INT32_MAX && y_num_min + bias_i < guard;
     if (ext_i != 0x7fffffff) {
         acc.best = sb - (double)ext_t;
         acc.best_i = ext_i;
