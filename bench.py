@@ -312,6 +312,10 @@ def rank_main(args: argparse.Namespace) -> int:
         if c3["k_basic_features_ms"] is not None and c3["k_width_integral_ms"] is not None:
             c3["total_ms"] = round(pass_ms + c3["k_basic_features_ms"] + c3["k_width_integral_ms"], 4)
             c3["Gsamples_per_s"] = round(n_samples / c3["total_ms"] / 1e6, 1)
+            # stand-alone roofline of the two feature kernels: one read of the samples + the record columns + one row
+            for key, row_bytes in (("k_basic_features", 36), ("k_width_integral", 52)):
+                b = 2 * n_samples + (29 + row_bytes) * len(records)
+                c3[key + "_frac"] = round(b / (c3[key + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # end to end through the plugin boundary: host arrays in, structured rows out (H2D + kernels + D2H)
         try:
             from waveformanalysis_amd.plugin_api import SimpleContext
