@@ -92,7 +92,13 @@ def test_one_walk_and_two_walk_candidate_paths(sess):
         sess.profile(True)
         got = sess.find_peaks(_lib.SRC_F32, **cfg)
         names = set(sess.profile_report())
-        assert "k_find_peaks_slots" in names and route in names, names
+        assert "k_find_peaks_staged" in names and route in names, names      # uniform records: the LDS-staged walk
+        sess.set_option("no_span", True)
+        sess.profile(True)
+        per_record = sess.find_peaks(_lib.SRC_F32, **cfg)
+        assert "k_find_peaks_slots" in set(sess.profile_report())             # any layout: one lane per record
+        sess.set_option("no_span", False)
+        assert per_record.tobytes() == got.tobytes()
         sess.set_option("no_peak_slots", True)
         sess.profile(True)
         two_walks = sess.find_peaks(_lib.SRC_F32, **cfg)

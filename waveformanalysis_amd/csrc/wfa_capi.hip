@@ -1085,9 +1085,16 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int signal_mode, int use_deriva
             if ((rc = c->peak_slot_pos.ensure((size_t)R * K * sizeof(int32_t)))) return rc;
             if ((rc = c->peak_slot_val.ensure((size_t)R * K * sizeof(double)))) return rc;
             LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_find_peaks_slots(c->stream, source, pv, rv, pp, K, counts, c->peak_slot_pos.as<int32_t>(),
-                                                  c->peak_slot_val.as<double>(), overflow));
-            if ((rc = t.end("k_find_peaks_slots"))) return rc;
+            hipError_t herr = hipSuccess;
+            // uniform records: the walk on LDS-staged groups (coalesced); any other layout: one lane per record
+            const bool staged = c->span_ok && !c->opt.no_span &&
+                                launch_find_peaks_staged(c->stream, source, pv, rv, pp, c->span_off0, c->span_L, K, counts,
+                                                         c->peak_slot_pos.as<int32_t>(), c->peak_slot_val.as<double>(), overflow, &herr);
+            WFA_HIP_CHECK(herr);
+            if (!staged)
+                WFA_HIP_CHECK(launch_find_peaks_slots(c->stream, source, pv, rv, pp, K, counts, c->peak_slot_pos.as<int32_t>(),
+                                                      c->peak_slot_val.as<double>(), overflow));
+            if ((rc = t.end(staged ? "k_find_peaks_staged" : "k_find_peaks_slots"))) return rc;
         } else {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_find_peaks(c->stream, source, false, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr));

@@ -8,6 +8,8 @@
 //
 // Reference lines are cited at each device function (paths relative to waveform_analysis/).
 
+#include <type_traits>
+
 #include "wfa_kernels.hpp"
 #include "wfa_numpy.hpp"
 #include "wfa_device.hpp"
@@ -2236,6 +2238,193 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks_slots(PoolView pool, 
     if (n_out > K) atomicOr(overflow, 1);
 }
 
+// The same single walk for uniform records, with coalesced reads: a wave stages a group of 64 >> gl_shift consecutive
+// records in LDS (16-byte loads, every byte of the pool read once) and 1 << gl_shift lanes share a record, each scanning
+// its own stretch of the detection signal.  _local_maxima_1d is local: a candidate is a rise, a plateau and a fall, so a
+// lane that starts with no open candidate at its first index finds exactly the candidates whose plateau STARTS in its
+// stretch, provided it follows an open one past the end of the stretch until it falls (a peak) or rises (the later
+// plateau start belongs to the lane behind).  Lanes are in position order, so are the record's candidates.
+struct StagedPeakArgs {
+    int64_t off0;      // first sample of record 0 in the pool
+    int32_t L;         // samples per record (multiple of 8)
+    int32_t gl_shift;  // lanes per record = 1 << gl_shift
+};
+
+template <int SRC>
+__global__ __launch_bounds__(kWave) void k_find_peaks_staged(PoolView pool, RecView rec, PeakParams pp, StagedPeakArgs sa,
+                                                             int K, int32_t* __restrict__ counts,
+                                                             int32_t* __restrict__ slot_pos, double* __restrict__ slot_val,
+                                                             int* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int ES = SRC == WFA_SRC_RAW ? 2 : 4;
+    const int lane = lane_id();
+    const int L = sa.L;
+    const int GL = 1 << sa.gl_shift, RW = kWave >> sa.gl_shift;
+    const int g = lane >> sa.gl_shift, k = lane & (GL - 1);
+    // all of a group's loads (samples and record columns) are issued before anything waits for one of them; the loop
+    // runs once per wave with the launcher's grid (it is written for any grid)
+    const int64_t n_groups = (rec.R + RW - 1) / RW;
+    const u4* __restrict__ src0 = reinterpret_cast<const u4*>(SRC == WFA_SRC_RAW ? (const void*)pool.u16 : (const void*)pool.f32) +
+                                  (sa.off0 * ES >> 4);
+    const int gchunks = L * ES >> 4;  // 16-byte chunks per record
+    u4 pf[16];
+    double nx_bl = 0.0;
+    int nx_pol = 0;
+    auto fetch = [&](int64_t grp) __attribute__((always_inline)) {
+        const int64_t q0 = grp * RW;
+        const int nr = (int)(rec.R - q0 < RW ? rec.R - q0 : RW);
+        const int chunks = nr * gchunks;  // <= 1024: 16 KiB per wave
+        const u4* src = src0 + q0 * gchunks;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = t * kWave + lane;
+            pf[t] = src[c < chunks ? c : 0];
+        }
+        const int64_t q = g < nr ? q0 + g : q0;
+        nx_bl = rec.baseline[q];
+        nx_pol = rec.pol[q];
+    };
+    int64_t grp = blockIdx.x;
+    if (grp < n_groups) fetch(grp);
+    for (; grp < n_groups; grp += gridDim.x) {
+    const int64_t r0 = grp * RW;
+    const int nrec = (int)(rec.R - r0 < RW ? rec.R - r0 : RW);
+    {
+        const int chunks = nrec * gchunks;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = t * kWave + lane;
+            if (c < chunks) reinterpret_cast<u4*>(s_stage)[c] = pf[t];
+        }
+    }
+    const double me_bl = nx_bl;
+    const int me_pol = nx_pol;
+    if (grp + gridDim.x < n_groups) fetch(grp + gridDim.x);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool valid = g < nrec;
+    const int64_t r = valid ? r0 + g : r0;
+    SignalAt<SRC> S;
+    {
+        const int64_t off = sa.off0 + r * L;  // uniform records: nothing to load
+        S.off0 = off;
+        S.pv = pool;
+        S.xu = pool.u16 ? pool.u16 + off : nullptr;
+        S.xf = pool.f32 ? pool.f32 + off : nullptr;
+        S.b64 = me_bl;
+        S.b32 = (float)me_bl;
+        S.positive = me_pol == WFA_POL_POSITIVE;
+        S.use_derivative = pp.use_derivative;
+        S.rows = pp.rows;
+        S.L = L;
+        S.n = pp.use_derivative ? L - 1 : L;
+    }
+    const int n = S.n, deriv = S.use_derivative;
+    const uint16_t* lu = reinterpret_cast<const uint16_t*>(s_stage) + g * L;
+    const float* lf = reinterpret_cast<const float*>(s_stage) + g * L;
+    auto wv = [&](int m) { return SRC == WFA_SRC_RAW ? (float)lu[m] : lf[m]; };
+
+    constexpr int kStash = 4;  // candidates a lane keeps (ringing behind a large pulse gives a lane three or four)
+    int n_mine = 0;
+    int st_pos[kStash] = {0, 0, 0, 0};
+    double st_val[kStash] = {0.0, 0.0, 0.0, 0.0};
+    auto on_peak = [&](int c_start, int i, double c_val) {  // plateau [c_start, i - 1] ended by a fall at i
+        const int peak = (c_start + i - 1) / 2;
+        bool keep = c_val >= pp.hmin;
+        if (keep && pp.has_threshold) {
+            const double lt = c_val - S.det(peak - 1), rt = c_val - S.det(peak + 1);
+            keep = (lt < rt ? lt : rt) >= pp.tmin;
+        }
+        if (keep) {
+#pragma unroll
+            for (int q = 0; q < kStash; ++q)
+                if (n_mine == q) { st_pos[q] = peak; st_val[q] = c_val; }
+            ++n_mine;
+        }
+    };
+    // The detection value in one of five wave-uniform forms (SignalAt::det_of): chosen once per group, so that the walk
+    // below is compiled per form and carries no mode tests (they were 54 scalar instructions and 15 branches per step).
+    auto walk = [&](auto det2, auto deriv_tag) __attribute__((always_inline)) {
+        constexpr int DERIV = decltype(deriv_tag)::value;
+        if (!(valid && n >= 3)) return;
+        int seg = (n + GL - 1) >> sa.gl_shift;
+        seg = (seg + 3) & ~3;
+        const int a = k * seg, b = a + seg < n ? a + seg : n;
+        if (a >= b) return;
+        bool have = false;
+        int c_start = 0;
+        double c_val = 0.0;
+        double x_prev = a > 0 ? det2(wv(a - 1), DERIV ? wv(a) : 0.f) : 0.0;
+        float w_prev = wv(a);
+        // the plateau state machine of scan_candidates as selects: one (rare) divergent block per step, for the lanes
+        // whose candidate ends at this step
+        for (int i0 = a; i0 < b; i0 += 4) {
+            float wn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = i0 + u + DERIV;
+                wn[u] = wv(m < L ? m : L - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                const double x = DERIV ? det2(w_prev, wn[u]) : det2(wn[u], 0.f);
+                w_prev = DERIV ? wn[u] : w_prev;
+                const bool in = i < b;
+                const bool act = in && i > 0;
+                const bool fall = act && have && x < c_val;
+                if (fall) on_peak(c_start, i, c_val);
+                const bool set = act && (have ? x > c_val : (x_prev < x && i < n - 1));
+                have = (have && !fall) || (act && set);
+                c_start = set ? i : c_start;
+                c_val = set ? x : c_val;
+                x_prev = in ? x : x_prev;
+            }
+        }
+        for (int i = b; __ballot(have && i < n) != 0; ++i) {  // an open candidate is followed to its end
+            const bool go = have && i < n;
+            const int m = go ? i : 0;
+            const double x = det2(wv(m), DERIV ? wv(m + 1 < L ? m + 1 : L - 1) : 0.f);
+            if (go && x < c_val) on_peak(c_start, i, c_val);
+            have = go && x == c_val;  // a fall ends it as a peak, a rise as the start of the next lane's plateau
+        }
+    };
+    {
+        const float b32 = S.b32;
+        const double b64 = S.b64;
+        const uint32_t sgn = S.positive ? 0u : 0x80000000u;  // signal = +-(w - baseline) in float32
+        auto rec_val = [=](float w) { return (double)__uint_as_float(__float_as_uint(w - b32) ^ sgn); };
+        if (!S.rows) {
+            if (deriv) walk([=](float w0, float w1) { return rec_val(w1) - rec_val(w0); }, std::integral_constant<int, 1>{});
+            else walk([=](float w0, float) { return rec_val(w0) - 0.0; }, std::integral_constant<int, 0>{});
+        } else if (!deriv) {
+            walk([=](float w0, float) { return b64 - (double)w0; }, std::integral_constant<int, 0>{});
+        } else if (SRC == WFA_SRC_RAW || S.rows == WFA_PEAK_SIGNAL_ROWS_F64) {
+            walk([=](float w0, float w1) { return -((double)w1 - (double)w0); }, std::integral_constant<int, 1>{});
+        } else {
+            walk([=](float w0, float w1) { return (double)(-(w1 - w0)); }, std::integral_constant<int, 1>{});
+        }
+    }
+    // slots of the record in lane order
+    int incl = n_mine;
+    for (int d = 1; d < GL; d <<= 1) {
+        const int o = __shfl_up(incl, d, GL);
+        if (k >= d) incl += o;
+    }
+    const int base = incl - n_mine;
+    const int total = __shfl(incl, GL - 1, GL);
+    if (valid) {
+        const int64_t sb = r * K;
+#pragma unroll
+        for (int q = 0; q < kStash; ++q)
+            if (n_mine > q && base + q < K) { slot_pos[sb + base + q] = st_pos[q]; slot_val[sb + base + q] = st_val[q]; }
+        if (k == 0) counts[r] = total;
+        if (n_mine > kStash || (k == 0 && total > K)) atomicOr(overflow, 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next group's LDS writes stay behind this group's reads
+    }
+}
+
 __global__ __launch_bounds__(kPeakBlock) void k_peak_compact(int64_t R, int K, const int32_t* __restrict__ counts,
                                                              const int64_t* __restrict__ cand_start,
                                                              const int32_t* __restrict__ slot_pos,
@@ -2573,6 +2762,34 @@ hipError_t launch_find_peaks_slots(hipStream_t st, int source, const PoolView& p
     else
         hipLaunchKernelGGL((k_find_peaks_slots<WFA_SRC_F32>), dim3(grid), dim3(kPeakBlock), 0, st, pool, rec, pp, K, counts, slot_pos, slot_val, overflow);
     return hipGetLastError();
+}
+
+// false: the layout is not covered (the lane-per-record walk runs instead)
+bool launch_find_peaks_staged(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                              int64_t off0, int L, int K, int32_t* counts, int32_t* slot_pos, double* slot_val, int* overflow,
+                              hipError_t* err) {
+    *err = hipSuccess;
+    if (rec.R == 0 || L < 8 || (L & 7) || (off0 & 7)) return false;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return false;
+    const int cap = source == WFA_SRC_RAW ? 8192 : 4096;  // samples staged per wave: 16 KiB of LDS
+    int sh = 0;
+    while (sh < 6 && (int64_t)(kWave >> sh) * L > cap) ++sh;
+    if ((int64_t)(kWave >> sh) * L > cap) return false;
+    while (sh < 6 && (L >> sh) > 256) ++sh;  // at most 256 samples per lane
+    StagedPeakArgs sa{off0, L, sh};
+    const int RW = kWave >> sh;
+    const size_t lds = (size_t)RW * L * (source == WFA_SRC_RAW ? 2 : 4) + 16;
+    const int64_t n_groups = (rec.R + RW - 1) / RW;
+    // one group per wave: a resident-set grid of persistent waves (each with its next group in flight) measured 2.38 ms
+    // against 1.56 ms -- the walks of a group end at very different times (open candidates are followed past the lane's
+    // stretch), and many small blocks balance that better than the prefetch hides latency
+    const unsigned grid = (unsigned)n_groups;
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_find_peaks_staged<WFA_SRC_RAW>), dim3(grid), dim3(kWave), lds, st, pool, rec, pp, sa, K, counts, slot_pos, slot_val, overflow);
+    else
+        hipLaunchKernelGGL((k_find_peaks_staged<WFA_SRC_F32>), dim3(grid), dim3(kWave), lds, st, pool, rec, pp, sa, K, counts, slot_pos, slot_val, overflow);
+    *err = hipGetLastError();
+    return true;
 }
 
 hipError_t launch_peak_compact(hipStream_t st, int64_t R, int K, const int32_t* counts, const int64_t* cand_start,
