@@ -171,6 +171,11 @@ __device__ __forceinline__ void put_f64(uint32_t* row, int dword, double v) {
 // ---- exact-integer Savitzky-Golay building blocks (see wfa_kernels.hip, "K7 fast path") -----------------------
 typedef short wfa_s2 __attribute__((ext_vector_type(2)));
 
+typedef unsigned short wfa_us2 __attribute__((ext_vector_type(2)));
+// acc + lo(pair) * lo(coef) + hi(pair) * hi(coef) on unsigned 16-bit halves
+__device__ __forceinline__ uint32_t udot2_acc(uint32_t pair, uint32_t coef, uint32_t acc) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(wfa_us2, pair), __builtin_bit_cast(wfa_us2, coef), acc, false);
+}
 __device__ __forceinline__ int sdot2_acc(uint32_t pair, uint32_t coef, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(wfa_s2, pair), __builtin_bit_cast(wfa_s2, coef), acc, false);
 }

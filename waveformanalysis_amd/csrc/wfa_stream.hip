@@ -45,6 +45,8 @@ struct StreamLds {  // per wave
     double thr[kWave];   // NaN thresholds / baselines stored as +inf: no hits
     double bl[kWave];    // given baselines (BLW == 0)
     int32_t tot[kWave];  // baseline sums (BLW > 0)
+    int32_t nz[kWave];   // -zhi: the addend that makes the sign of a numerator the candidate bit
+    int32_t nb[kWave];   // undecided integers below zhi (0 almost always)
     uint32_t eb[kWave];  // edge bits of the second pass
     uint32_t head[kWave][8];  // biased dwords: the first 16 samples of every record
     uint32_t tail[kWave][8];  // 16 samples that contain the last W samples of every record
@@ -141,6 +143,17 @@ __global__ __launch_bounds__(kBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {
         if (positive) { n0 = -n0; n1 = -n1; }  // Z = -(n.x - bias)
         cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
     }
+    // first tap alone (a 16 x 16 + 32 multiply-add that takes the addend from another register: the 2-address
+    // v_dot2c would need a copy of the addend per output), then the taps 1..W-1 as H pairs
+    int c0 = a.itab[0];
+    if (positive) c0 = -c0;
+    uint32_t cq[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+        int n0 = a.itab[2 * m + 1], n1 = a.itab[2 * m + 2];
+        if (positive) { n0 = -n0; n1 = -n1; }
+        cq[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
+    }
     const uint32_t fillb = (positive ? 0u : 0xffffffffu) ^ 0x80008000u;
     // threshold bound per lane (see "exact decision boundary" in do_tile)
     const double den = (double)a.den;
@@ -176,10 +189,72 @@ __global__ __launch_bounds__(kBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {
         thr_next = load_thr(span + nwaves);
         bl_next = load_bl(span + nwaves);
         {
+            // lane = record of the span: its baseline (the first BLW samples: 80 bytes the tile loads read again a few
+            // microseconds later, out of L2 / MALL) and its decision boundary, once per record -- inside the tile loop
+            // the same float64 arithmetic ran once per tile for all lanes (113 of ~540 vector instructions per tile)
             const bool dead = !(thr_cur == thr_cur) || (BLW == 0 && !(bl_cur == bl_cur));
-            lds->thr[lane] = dead ? __builtin_huge_val() : thr_cur;
+            const double thr_l = dead ? __builtin_huge_val() : thr_cur;
+            int tot_l = 0;
+            double b;
+            if (BLW) {
+                static_assert(BLW % 8 == 0 && BLW <= 64, "baseline window: whole 16-byte chunks");
+                const uint4* __restrict__ hp =
+                    reinterpret_cast<const uint4*>(a.pool + g_base + (int64_t)(lane < nrec ? lane : 0) * S);
+                uint32_t sum = 0;
+#pragma unroll
+                for (int c = 0; c < BLW / 8; ++c) {
+                    const uint4 h = hp[c];
+                    sum = udot2_acc(h.x, 0x00010001u, sum);
+                    sum = udot2_acc(h.y, 0x00010001u, sum);
+                    sum = udot2_acc(h.z, 0x00010001u, sum);
+                    sum = udot2_acc(h.w, 0x00010001u, sum);
+                }
+                tot_l = (int)sum;
+                // tot / BLW, correctly rounded: reciprocal product + one FMA correction step (equal to the division for
+                // every sum of 40 uint16 samples: tests/test_baseline_division_cpu.py)
+                const double td = (double)tot_l;
+                const double q0 = td * rbl;
+                const double q1 = __builtin_fma(__builtin_fma(-(double)BLW, q0, td), rbl, q0);
+                b = positive ? -q1 : q1;
+            } else {
+                b = positive ? -bl_cur : bl_cur;
+            }
+            // Exact decision boundary.  The reference masks  sig = +-(b - f32(y)) >= thr, i.e. (on the signed
+            // quantities used here)  f32(y) <= v  with  v = +-b - thr.  Let lo <= v < hi be the adjacent float32
+            // values around v: f32(y) <= v  <=>  y rounds to lo or below  <=>  y < (lo + hi) / 2.  With
+            // y = Z / den + eps (|eps * den| <= delta) the mask is  Z < zt  for  zt = (lo + hi) / 2 * den  (exact
+            // in float64), undecided only for integers within delta of zt: zl < Z < zh holds for at most one
+            // integer, which the reference's float64 code decides (rare path in do_tile).
+            const double v = b - thr_l;
+            const float f = (float)v;
+            const double fd = (double)f;
+            const uint32_t u = __float_as_uint(f);
+            const bool f_above = fd > v, f_pos = (u >> 31) == 0;
+            const uint32_t u_lo = f_above ? (f_pos ? u - 1u : u + 1u) : u;   // one float32 towards -inf
+            const uint32_t u_hi = f_above ? u : (f_pos ? u + 1u : u - 1u);   // one float32 towards +inf
+            const double zt = ((double)__uint_as_float(u_lo) + (double)__uint_as_float(u_hi)) * (0.5 * den);
+            double zl = floor(zt - delta), zh = ceil(zt + delta);
+            // v = fl(+-b - thr) stands for the real number +-b - thr.  If it lies (almost) on a float32 value the
+            // rounding of that subtraction decides the side: unless the subtraction was exact, take a band of one
+            // float32 spacing either side and let the float64 code decide; the same for |v| < 1 (bit stepping
+            // around zero)
+            const double av = fabs(v);
+            if (fabs(fd - v) <= av * 1e-11 || !(av >= 1.0)) {
+                const bool exact = fabs(b) >= fabs(thr_l) && ((b - v) - thr_l) == 0.0 && av >= 1.0;  // Fast2Sum
+                if (!exact) {
+                    const double w = fmax(av, 1.0) * (den * 2.4e-7) + 1.0;  // > den * ulp_f32(v)
+                    zl = floor(v * den - w);
+                    zh = ceil(v * den + w);
+                }
+            }
+            zh = fmin(fmax(zh + shift, -1073741824.0), 1073741824.0);  // NaN / -inf (no hits) -> -2^30
+            zl = fmin(fmax(zl + shift, -1073741825.0), 1073741823.0);
+            const int zhi = (int)zh;
+            lds->thr[lane] = thr_l;
             lds->bl[lane] = bl_cur;
-            lds->tot[lane] = 0;
+            lds->tot[lane] = tot_l;
+            lds->nz[lane] = -zhi;
+            lds->nb[lane] = zhi - 1 - (int)zl;  // integers strictly between zl and zh (0 almost always)
             lds->eb[lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
@@ -203,14 +278,11 @@ __global__ __launch_bounds__(kBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {
             auto do_tile = [&](int t, const Tile32& tile, const wfa_v4u& hl_r, const wfa_v4u& hr_r) {
                 const uint32_t cur[16] = {tile.q0.x, tile.q0.y, tile.q0.z, tile.q0.w, tile.q1.x, tile.q1.y, tile.q1.z, tile.q1.w,
                                           tile.q2.x, tile.q2.y, tile.q2.z, tile.q2.w, tile.q3.x, tile.q3.y, tile.q3.z, tile.q3.w};
-                // scalar: biased halo dwords (the last 6 samples before / the first 6 behind the tile) and the sum of
-                // the first 8 samples behind it (baseline of a record that starts in the last lane)
+                // scalar: biased halo dwords (the last 6 samples before / the first 6 behind the tile)
                 const bool t0 = t == 0;
                 const uint32_t hl1 = t0 ? fillb : (hl_r.y ^ 0x80008000u), hl2 = t0 ? fillb : (hl_r.z ^ 0x80008000u),
                                hl3 = t0 ? fillb : (hl_r.w ^ 0x80008000u);
                 const uint32_t hr0 = hr_r.x ^ 0x80008000u, hr1 = hr_r.y ^ 0x80008000u, hr2 = hr_r.z ^ 0x80008000u;
-                const uint32_t n8b = (hr_r.x & 0xffffu) + (hr_r.x >> 16) + (hr_r.y & 0xffffu) + (hr_r.y >> 16) +
-                                     (hr_r.z & 0xffffu) + (hr_r.z >> 16) + (hr_r.w & 0xffffu) + (hr_r.w >> 16) - 8u * 32768u;
                 const bool act = rl < nrec;
                 const int rli = act ? rl : 0;
                 const bool first = i0 == 0, last = i0 == S - kSpl;
@@ -226,69 +298,8 @@ __global__ __launch_bounds__(kBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {
                 E[20] = dpp_from_next_lane(hr1, E[4]);
                 E[21] = dpp_from_next_lane(hr2, E[5]);
 
-                // ---- baseline sum of the records that start in this tile, threshold bound of every lane ----
-                int nzhi, nband;
-                {
-                    double b;
-                    if (BLW) {
-                        // sums of the biased samples (x - 32768): all 32 of the lane, and its first 8
-                        int p4 = 0, f32s = 0;
-#pragma unroll
-                        for (int m = 0; m < 16; ++m) {
-                            f32s = sdot2_acc(E[3 + m], 0x00010001u, f32s);
-                            if (m == 3) p4 = f32s;
-                        }
-                        // first 8 samples of the next lane (lane 63: of the next tile, from the scalar halo)
-                        const int a1 = (int)dpp_from_next_lane(n8b, (uint32_t)p4);
-                        if (first && act) lds->tot[rl] = f32s + a1 + BLW * 32768;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // other lanes of the wave read it
-                        // tot / BLW, correctly rounded: reciprocal product + one FMA correction step (equal to the division for
-                        // every sum of 40 uint16 samples: tests/test_baseline_division_cpu.py)
-                        const double td = (double)lds->tot[rli];
-                        const double q0 = td * rbl;
-                        const double q1 = __builtin_fma(__builtin_fma(-(double)BLW, q0, td), rbl, q0);
-                        b = positive ? -q1 : q1;
-                    } else {
-                        b = positive ? -lds->bl[rli] : lds->bl[rli];
-                    }
-                    // Exact decision boundary.  The reference masks  sig = +-(b - f32(y)) >= thr, i.e. (on the signed
-                    // quantities used here)  f32(y) <= v  with  v = +-b - thr.  Let lo <= v < hi be the adjacent float32
-                    // values around v: f32(y) <= v  <=>  y rounds to lo or below  <=>  y < (lo + hi) / 2.  With
-                    // y = Z / den + eps (|eps * den| <= delta) the mask is  Z < zt  for  zt = (lo + hi) / 2 * den  (exact
-                    // in float64), undecided only for integers within delta of zt: zl < Z < zh holds for at most one
-                    // integer, which the reference's float64 code decides (rare path below).
-                    const double v = b - lds->thr[rli];
-                    const float f = (float)v;
-                    const double fd = (double)f;
-                    const uint32_t u = __float_as_uint(f);
-                    const bool f_above = fd > v, f_pos = (u >> 31) == 0;
-                    const uint32_t u_lo = f_above ? (f_pos ? u - 1u : u + 1u) : u;   // one float32 towards -inf
-                    const uint32_t u_hi = f_above ? u : (f_pos ? u + 1u : u - 1u);   // one float32 towards +inf
-                    const double zt = ((double)__uint_as_float(u_lo) + (double)__uint_as_float(u_hi)) * (0.5 * den);
-                    double zl = floor(zt - delta), zh = ceil(zt + delta);
-                    // v (almost) on a float32 value -- the in-stream baseline tot * (1 / BLW) may differ from the
-                    // reference's tot / BLW in the last bit -- or |v| < 1 (bit stepping around zero): a band of one
-                    // float32 spacing either side, decided by the float64 code
-                    // v = fl(+-b - thr) stands for the real number +-b - thr.  If it lies (almost) on a float32 value the
-                    // rounding of that subtraction decides the side: unless the subtraction was exact, take a band of one
-                    // float32 spacing either side and let the float64 code decide; the same for |v| < 1 (bit stepping
-                    // around zero)
-                    const double av = fabs(v);
-                    if (fabs(fd - v) <= av * 1e-11 || !(av >= 1.0)) {
-                        const double thr_l = lds->thr[rli];
-                        const bool exact = fabs(b) >= fabs(thr_l) && ((b - v) - thr_l) == 0.0 && av >= 1.0;  // Fast2Sum
-                        if (!exact) {
-                            const double w = fmax(av, 1.0) * (den * 2.4e-7) + 1.0;  // > den * ulp_f32(v)
-                            zl = floor(v * den - w);
-                            zh = ceil(v * den + w);
-                        }
-                    }
-                    zh = fmin(fmax(zh + shift, -1073741824.0), 1073741824.0);  // NaN / -inf (no hits) -> -2^30
-                    zl = fmin(fmax(zl + shift, -1073741825.0), 1073741823.0);
-                    const int zhi = (int)zh;
-                    nzhi = -zhi;
-                    nband = zhi - 1 - (int)zl;  // integers strictly between zl and zh (0 almost always)
-                }
+                // ---- threshold bound of the lane's record (from the span prologue) ----
+                int nzhi = lds->nz[rli], nband = lds->nb[rli];
 
                 // ---- deposits for the edge evaluation after the span ----
                 if (!(dbg & 2)) {
@@ -331,11 +342,15 @@ __global__ __launch_bounds__(kBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {
                         const int ws = jj - H + 6;  // first window sample, counted from E[8h]'s first sample (>= 1)
                         // (no inline-asm VOP3P first tap here: gfx950 needs wait states between a dot instruction and a
                         // different VALU instruction that reads its result, and hipcc pads only the instructions it knows)
-                        int acc = addend;
+                        // sample ws is the low half of E[8h + ws / 2] (ws even) or of Sh[(ws - 1) / 2] (ws odd); the pairs
+                        // (ws + 1 + 2m, ws + 2 + 2m) then sit in the array of the other parity
+                        const uint32_t x0 = (ws & 1) == 0 ? E[8 * h + ws / 2] : Sh[(ws - 1) / 2];
+                        int acc;
+                        asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(acc) : "v"(x0), "s"(c0), "v"(addend));
 #pragma unroll
-                        for (int m = 0; m < NP; ++m) {
-                            const uint32_t pair = (ws & 1) == 0 ? E[8 * h + ws / 2 + m] : Sh[(ws - 1) / 2 + m];
-                            acc = sdot2_acc(pair, cpm[m], acc);
+                        for (int m = 0; m < H; ++m) {
+                            const uint32_t pair = (ws & 1) == 0 ? Sh[ws / 2 + m] : E[8 * h + (ws + 1) / 2 + m];
+                            acc = sdot2_acc(pair, cq[m], acc);
                         }
                         return acc;
                     };
