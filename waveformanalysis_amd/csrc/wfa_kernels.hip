@@ -290,6 +290,33 @@ __device__ __forceinline__ void sg_chunk_numerators(const uint32_t (&E)[12], con
     }
 }
 
+// The same 8 numerators plus `addend`, first tap alone: a 16 x 16 + 32 multiply-add takes the addend from another
+// register (the 2-address v_dot2c needs its accumulator initialised: one v_mov per output), then the taps 1 .. W - 1 as
+// H pairs.  c0 = n[0], cq[m] = (n[2m + 1], n[2m + 2]) packed.
+template <int W>
+__device__ __forceinline__ void sg_chunk_numerators_add(const uint32_t (&E)[12], int c0, const uint32_t* cq, int addend,
+                                                        int (&Z)[8]) {
+    constexpr int H = W / 2;
+    uint32_t S[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) S[k] = __builtin_amdgcn_alignbit(E[k + 1], E[k], 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ws = j - H + 8;  // first sample of the window, counted from E[0]'s first sample (>= 1)
+        // sample ws is the low half of E[ws / 2] (ws even) or of S[(ws - 1) / 2] (ws odd); the pairs behind it sit in
+        // the array of the other parity
+        const uint32_t x0 = (ws & 1) == 0 ? E[ws / 2] : S[(ws - 1) / 2];
+        int acc;
+        asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(acc) : "v"(x0), "s"(c0), "v"(addend));
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const uint32_t pair = (ws & 1) == 0 ? S[ws / 2 + m] : E[(ws + 1) / 2 + m];
+            acc = sdot2_acc(pair, cq[m], acc);
+        }
+        Z[j] = acc;
+    }
+}
+
 // PF = tiles of the next record kept in flight per wave (PF x 1 KiB)
 template <int W, bool FUSED_BASELINE, int PF>
 __global__ __launch_bounds__(kBlock) void k_sg_mask(PoolView pool, RecView rec, SgParams sg, MaskParams mp) {
@@ -1115,7 +1142,6 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
                                                              int4* __restrict__ desc, int64_t n_hits,
                                                              uint8_t* __restrict__ out) {
     constexpr int H = W / 2;
-    constexpr int NP = H + 1;
     __shared__ int s_len[kRowsHits];
     __shared__ int s_perm[kRowsHits];
     const int q = threadIdx.x & 7;
@@ -1151,13 +1177,10 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     if (live) d = desc[h];
     const bool work = live && d.w == 0;
 
-    uint32_t cpm[NP];
+    const int c0 = sg.itab[0];
+    uint32_t cq[H];
 #pragma unroll
-    for (int m = 0; m < NP; ++m) {
-        const int n0 = sg.itab[2 * m];
-        const int n1 = (2 * m + 1 < W) ? sg.itab[2 * m + 1] : 0;
-        cpm[m] = ((uint32_t)n0 & 0xffffu) | ((uint32_t)n1 << 16);
-    }
+    for (int m = 0; m < H; ++m) cq[m] = ((uint32_t)sg.itab[2 * m + 1] & 0xffffu) | ((uint32_t)sg.itab[2 * m + 2] << 16);
     const int bias_i = 32768 * sg.den;
     const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
 
@@ -1227,8 +1250,8 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
             E[k] = dpp_from_prev_lane(0u, E[4 + k]);
             E[8 + k] = dpp_from_next_lane(0u, E[4 + k]);
         }
-        int Z[8];
-        sg_chunk_numerators<W>(E, cpm, Z);
+        int Z[8];  // numerators of the unbiased samples: n . x
+        sg_chunk_numerators_add<W>(E, c0, cq, bias_i, Z);
         const bool lane_ok = q >= 1 && q <= 6 && mine <= c_last;
         const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
         // a sample outside the window gets t = +inf: it never wins the extremum and its signal is -inf, clamped to 0
@@ -1246,7 +1269,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool in = lane_ok && (unsigned)(rel0 + j) < (unsigned)wlen;
-            const int y_num = Z[j] + bias_i;
+            const int y_num = Z[j];
             const float y32 = (float)((double)y_num * sg.rden);
             // (the compiler branches around this block when no lane of the wave has sample j in its window; forcing a
             // straight-line loop measured 0.475 ms against 0.456: short hits leave most of a round's slots empty)
@@ -1271,7 +1294,7 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
             do_round(c, cur);
         }
     }
-    need_literal |= y_num_min != INT32_MAX && y_num_min + bias_i < guard;
+    need_literal |= y_num_min < guard;
     if (ext_i != 0x7fffffff) {
         acc.best = sb - (double)ext_t;
         acc.best_i = ext_i;
