@@ -132,6 +132,22 @@ def test_hip_plugins_inside_reference_context(ref_env):
     for col in ("area", "height", "amp", "max_abs_diff", "timestamp"):
         np.testing.assert_array_equal(cdf[col].to_numpy(), df[col].to_numpy())
 
+    # the reference's event stages downstream of `df` (GroupedEventsPlugin / PairedEventsPlugin,
+    # cpu/event_analysis.py:23-66,109-144) consume the HIP tables unchanged: same frames as the all-CPU run,
+    # saved and re-loaded through the same cache machinery, under lineage keys that differ
+    import pandas as pd
+
+    cfg = {"n_channels": 16, "start_channel_slice": 0, "time_window_ns": 2000.0, "use_numba": False}
+    for c in (ctx, cpu):
+        c.set_config(cfg)
+    for name in ("df_events", "df_paired"):
+        got, want = ctx.get_data("run", name), cpu.get_data("run", name)
+        assert isinstance(got, pd.DataFrame) and len(got) == len(want)
+        pd.testing.assert_frame_equal(got.reset_index(drop=True), want.reset_index(drop=True))
+        assert cpu.key_for("run", name) != ctx.key_for("run", name)
+    assert len(ctx.get_data("run", "df_events")) > 5                              # 15 events of 1..5 records
+    assert OracleSession.calls == 2                                                # nothing was recomputed on the way
+
 
 class OracleStreamSession:
     """Stand-in for a borrowed DeviceSession on the streaming path (upload, enqueue, wait): answers with the oracle."""
