@@ -847,6 +847,10 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
     constexpr int NP = H + 1;
     __shared__ float s_edge[kWavesPerBlock][kWave][2 * H];
     __shared__ int32_t etab[2 * H * W];
+    // a tile's 512 float32 outputs on their way out: a lane holds 8 consecutive values (32 bytes), and stored as they
+    // are every store instruction writes 16 bytes at a 32-byte stride; through this buffer each of the two store
+    // instructions writes one contiguous KiB
+    __shared__ __attribute__((aligned(16))) float s_out[kWavesPerBlock][512];
     for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = sg.itab[W + k];
     __syncthreads();
     const int lane = lane_id();
@@ -991,7 +995,17 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
                 }
             }
             if (!PADDED) {
-                if (in_span) {
+                if (t * 512 + 512 <= span_samples) {  // whole tile inside the span (wave-uniform)
+                    float4* stage = reinterpret_cast<float4*>(&s_out[wv][0]);
+                    stage[2 * lane] = make_float4(y[0], y[1], y[2], y[3]);
+                    stage[2 * lane + 1] = make_float4(y[4], y[5], y[6], y[7]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const float4 a = stage[lane], b = stage[64 + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    float4* dst = reinterpret_cast<float4*>(out_span + t * 512);
+                    dst[lane] = a;
+                    dst[64 + lane] = b;
+                } else if (in_span) {
                     float4* dst = reinterpret_cast<float4*>(out_span + pos);
                     dst[0] = make_float4(y[0], y[1], y[2], y[3]);
                     dst[1] = make_float4(y[4], y[5], y[6], y[7]);
