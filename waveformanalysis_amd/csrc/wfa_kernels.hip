@@ -1002,9 +1002,10 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     const float4 a = stage[lane], b = stage[64 + lane];
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    float4* dst = reinterpret_cast<float4*>(out_span + t * 512);
-                    dst[lane] = a;
-                    dst[64 + lane] = b;
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    f4v* dst = reinterpret_cast<f4v*>(out_span + t * 512);
+                    __builtin_nontemporal_store(f4v{a.x, a.y, a.z, a.w}, &dst[lane]);  // written once, read by a later kernel
+                    __builtin_nontemporal_store(f4v{b.x, b.y, b.z, b.w}, &dst[64 + lane]);
                 } else if (in_span) {
                     float4* dst = reinterpret_cast<float4*>(out_span + pos);
                     dst[0] = make_float4(y[0], y[1], y[2], y[3]);
