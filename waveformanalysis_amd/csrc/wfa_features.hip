@@ -377,9 +377,6 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
         if (grp + nwaves < n_groups) fetch(grp + nwaves);  // in flight while this group is reduced
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         FW_T(1);  // row store + prefetch issue
-#ifdef WFA_FW_NOCOMPUTE
-        if (fw.L > 0) { prow[0] = smp[lane]; continue; }
-#endif
 
         const bool valid = g < nrec;
         const int64_t r = r0 + g;
