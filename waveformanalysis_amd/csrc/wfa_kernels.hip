@@ -1014,8 +1014,9 @@ __global__ __launch_bounds__(kBlock) void k_savgol_span(PoolView pool, RecView r
             } else if (in_span && i0 < L) {  // packed output: record rl of the span, sample i0 ...
                 float* dst = out_span + (int64_t)rl * L + i0;
                 if (i0 + 8 <= L && ((g_out + (int64_t)rl * L + i0) & 3) == 0) {
-                    reinterpret_cast<float4*>(dst)[0] = make_float4(y[0], y[1], y[2], y[3]);
-                    reinterpret_cast<float4*>(dst)[1] = make_float4(y[4], y[5], y[6], y[7]);
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f4v{y[0], y[1], y[2], y[3]}, reinterpret_cast<f4v*>(dst));
+                    __builtin_nontemporal_store(f4v{y[4], y[5], y[6], y[7]}, reinterpret_cast<f4v*>(dst) + 1);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
