@@ -1144,9 +1144,9 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecV
     write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
 }
 
-// fast path: 8 lanes per hit.  Lane q of a group loads the aligned 16-byte chunk (c - 1 + q); lanes
-// 1..6 produce the 8 outputs of their chunk from exact integer numerators (halo over DPP), lanes 0 and
-// 7 only provide halo.  48 window samples per round, one coalesced 128-byte read per group.
+// fast path: 8 lanes per hit.  Lane q of a group loads the aligned 16-byte chunk (c + q) and produces its 8 outputs
+// from exact integer numerators (halo over DPP; the chunks either side of the round from a second load that lanes 0
+// and 7 use).  64 window samples per round, one coalesced 128-byte read per group (+ the two halo chunks).
 // Hit windows are strongly bimodal (fragments of a few samples vs. pulses of 100-300), and a wave iterates
 // as long as its longest hit.  Each 1024-thread block therefore ranks its 128 hits by window length in
 // LDS first, so that the 8 hits sharing a wave need about the same number of rounds.
@@ -1252,23 +1252,27 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     // outside [0, c_last + 1] only feed samples that are not in the window (record edges, finished groups); the pool
     // buffer has 256 B of slack behind its end
     const int64_t c_hi_load = has_int ? c_last + 1 : 0;
-    auto load_round = [&](int64_t c) {
-        int64_t m = c - 1 + q;
-        m = m < 0 ? 0 : (m > c_hi_load ? c_hi_load : m);
-        return p16[m];
-    };
-    auto do_round = [&](int64_t c, const uint4& v) {
-        const int64_t mine = c - 1 + q;
+    // all 8 lanes of a group evaluate a chunk (64 window samples per round): the halo in front of the round's first
+    // chunk and behind its last one comes from a second load that only lanes 0 and 7 need (the others read their own
+    // chunk again, an L1 hit).  With lanes 0 and 7 as pure halo providers a round covered 48 samples for the same
+    // per-round cost.
+    auto clampc = [&](int64_t m) { return m < 0 ? (int64_t)0 : (m > c_hi_load ? c_hi_load : m); };
+    auto load_own = [&](int64_t c) { return p16[clampc(c + q)]; };
+    auto load_edge = [&](int64_t c) { return p16[clampc(q == 0 ? c - 1 : (q == 7 ? c + 8 : c + q))]; };
+    auto do_round = [&](int64_t c, const uint4& v, const uint4& ve) {
+        const int64_t mine = c + q;
         uint32_t E[12];
         E[4] = v.x ^ 0x80008000u; E[5] = v.y ^ 0x80008000u; E[6] = v.z ^ 0x80008000u; E[7] = v.w ^ 0x80008000u;
+        const uint32_t X[4] = {ve.x ^ 0x80008000u, ve.y ^ 0x80008000u, ve.z ^ 0x80008000u, ve.w ^ 0x80008000u};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            E[k] = dpp_from_prev_lane(0u, E[4 + k]);
-            E[8 + k] = dpp_from_next_lane(0u, E[4 + k]);
+            const uint32_t pv = dpp_from_prev_lane(0u, E[4 + k]), nv = dpp_from_next_lane(0u, E[4 + k]);
+            E[k] = q == 0 ? X[k] : pv;
+            E[8 + k] = q == 7 ? X[k] : nv;
         }
         int Z[8];  // numerators of the unbiased samples: n . x
         sg_chunk_numerators_add<W>(E, c0, cq, bias_i, Z);
-        const bool lane_ok = q >= 1 && q <= 6 && mine <= c_last;
+        const bool lane_ok = mine <= c_last;
         const int rel0 = (int)(mine * 8 - g0);  // window-relative index of this chunk's sample 0
         // a sample outside the window gets t = +inf: it never wins the extremum and its signal is -inf, clamped to 0
         const int idx0 = ilo + rel0;
@@ -1296,18 +1300,19 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
             acc.sum += fmax(sb - (double)t, 0.0);
         }
     };
-    // one chunk in flight ahead of the round being evaluated; a ring of 3 (two ahead) measured 0.480 ms against 0.472:
-    // the kernel is bound by instruction issue, not by the latency of its loads
+    // one round's loads in flight ahead of the round being evaluated; a ring of 3 (two ahead) measured 0.480 ms against
+    // 0.472: the kernel is bound by instruction issue, not by the latency of its loads
     {
-        uint4 v = load_round(c_first);
-        for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 6) {
-            const uint4 cur = v;
-            // the scheduler must not lift the next load above the reads of `v`: the compiler cannot count a load that
+        uint4 v = load_own(c_first), ve = load_edge(c_first);
+        for (int64_t c = c_first; __ballot(c <= c_last) != 0; c += 8) {
+            const uint4 cur = v, cur_e = ve;
+            // the scheduler must not lift the next loads above the reads of `v`: the compiler cannot count a load that
             // is in flight across the back-edge and would wait for `vmcnt(0)`, i.e. for the prefetch it has just issued
             __builtin_amdgcn_sched_barrier(0);
-            v = load_round(c + 6);
+            v = load_own(c + 8);
+            ve = load_edge(c + 8);
             __builtin_amdgcn_sched_barrier(0);
-            do_round(c, cur);
+            do_round(c, cur, cur_e);
         }
     }
     need_literal |= y_num_min < guard;
