@@ -154,3 +154,21 @@ def test_plugin_record_id_indirection_and_errors():
     with pytest.raises(RuntimeError, match="峰高计算方法"):
         SimpleContext({"hit": {"wave_source": "records", "height_method": "nope"}}, data,
                       plugins=[HipHitFinderPlugin()]).get_data("run", "hit")
+
+
+@pytest.mark.parametrize("L,n", [(24, 900), (64, 500), (104, 300), (520, 200), (1000, 130), (2048, 66), (4000, 33), (8192, 9)])
+def test_staged_candidate_walk_over_record_lengths(sess, L, n):
+    """The LDS-staged candidate walk (k_find_peaks_staged) for 1..64 lanes per record, both sources, with and without
+    the derivative: the oracle's rows, and the same bytes as the lane-per-record walk (`no_span`)."""
+    rec, pool = synth.make_run(n, "v1725", cfg=50 + L % 11, L=L)
+    filt = O.filter_wave_pool_uniform(pool, L) if L >= 11 else pool.astype(np.float32)
+    for src, p in ((_lib.SRC_F32, filt), (_lib.SRC_RAW, pool)):
+        sess.upload_pool(p)
+        sess.upload_records(rec, 0.0)
+        for cfg in (dict(height=6.0, prominence=0.5, width=1), dict(use_derivative=False, height=8.0, prominence=1.0, width=2),
+                    dict(height=1.0, prominence=0.1, width=0, distance=5)):
+            got = sess.find_peaks(src, **cfg)
+            G.assert_struct_equal(got, O.find_peak_hits(rec, p, **cfg), what=f"L {L} src {src} {cfg}")
+            sess.set_option("no_span", True)
+            assert sess.find_peaks(src, **cfg).tobytes() == got.tobytes()
+            sess.set_option("no_span", False)
