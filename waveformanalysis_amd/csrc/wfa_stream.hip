@@ -585,7 +585,11 @@ bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_st
 
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a) {
     int64_t g = (a.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int rounds = 3;  // rounds of the resident set: shorter blocks let the dispatcher even out the tail
+    // one span per wave up to 64 rounds of the resident set: the dispatcher evens out the tail best with the smallest
+    // blocks (v1725, 19 531 spans: 3 / 8 rounds / one span per wave = 0.514 / 0.502 / 0.499 ms in one run; persistent
+    // waves with a hand-balanced last round of smaller spans: 0.53; spans of 32 records: 0.60-0.64 -- a span's fixed
+    // costs, prologue + first tile + flush, are ~19 us of its 86)
+    const int rounds = 64;
     const int64_t resident = (int64_t)rounds * 256 * kRunsOcc;
     if (g < 1) g = 1;
     if (g > resident) g = resident;
