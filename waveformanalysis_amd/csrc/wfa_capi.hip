@@ -236,7 +236,9 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         const int64_t held = (int64_t)std::min(c->hit_out.cap / 60, c->hit_desc.cap / sizeof(int4));
         const int64_t bound = c->last_hits + c->last_hits / 8 + 4096;
         const bool spec = c->last_hits >= 0 && held >= bound && !c->opt.no_speculate && attempt == 0;
-        int64_t ev_want = spec ? 2 * bound : std::max<int64_t>(2 * bound, R * 8 + 4096);
+        // every span owns a fixed slot of the event buffer (8 KiB: 160 MB per 10^9 samples, only the lines that hold
+        // events are ever touched)
+        const int64_t ev_want = ns * sg_runs32_event_slot();
         if ((int64_t)(c->run_ev.cap / sizeof(uint32_t)) < ev_want)
             if ((rc = c->run_ev.ensure((size_t)ev_want * sizeof(uint32_t)))) return rc;
         RunsParams rn{};
@@ -329,11 +331,9 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
             c->no_runs32 = true;
             return WFA_OK;
         }
-        if (flags & 2) {  // event buffer too small: the cursor kept counting, size it and stream again
-            const int64_t need = (int64_t)ctl[0] + (int64_t)ctl[0] / 8 + 4096;
-            if ((rc = c->run_ev.ensure((size_t)need * sizeof(uint32_t)))) return rc;
-            c->last_hits = (int64_t)ctl[0] / 2;
-            continue;
+        if (flags & 2) {  // a span's patched events outgrew its slot (cannot happen for W <= 11): general route
+            c->no_runs32 = true;
+            return WFA_OK;
         }
         c->last_hits = total;
         if (spec && total <= bound) {
@@ -998,12 +998,12 @@ int wfa_hits_wait(wfa_ctx* c, int64_t* n_hits) {
         c->pending = false;
         const int64_t total = *c->h_total;
         const bool runs_bad = c->pend.runs32 && (c->h_total[2] & 0xffffffffll) != 0;  // event buffers overflowed
-        if (runs_bad && (c->h_total[2] & 1)) c->no_runs32 = true;
+        if (runs_bad) c->no_runs32 = true;  // a span outgrew its LDS buffer or its slot: the general route from now on
         if (total <= c->pend.bound && !runs_bad) {
             c->last_hits = total;
             c->n_hits = total;
         } else {  // more rows than the speculative launch covered: the exact route, now
-            c->last_hits = runs_bad ? std::max<int64_t>(total, c->h_total[1] / 2) : total;
+            c->last_hits = total;
             const auto p = c->pend;
             if ((rc = run_hits(c, p.source, p.fused_bl, p.bl_start, p.bl_end, p.le, p.re, p.max_len, n_hits))) return rc;
             return WFA_OK;

@@ -214,6 +214,7 @@ bool sg_mask_span16_supported(const SgParams& sg, int L);
 hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl);
+int64_t sg_runs32_event_slot();  // events of the buffer every span owns
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a);
 hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,
                                const int64_t* span_row0, int64_t cap, int4* desc);
