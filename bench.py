@@ -172,6 +172,15 @@ def rank_main(args: argparse.Namespace) -> int:
     # ---- synthetic chunk of this rank (channel shard = its own seed) ---------------------------------
     t0 = time.perf_counter()
     records, pool = synth.make_run(args.records, args.preset, cfg=100 + rank)
+    if world > 1:
+        # channel sharding: rank r holds hardware channels [r C / N, (r + 1) C / N) of the preset's C channels,
+        # so the gathered hit table is one run over all of them for event grouping
+        n_boards, ch_per_board = synth.PRESETS[args.preset][2], synth.PRESETS[args.preset][3]
+        total_ch = n_boards * ch_per_board
+        per_rank = max(1, total_ch // world)
+        flat = (records["board"].astype(np.int64) * ch_per_board + records["channel"]) % per_rank + rank * per_rank
+        flat %= total_ch
+        records["board"], records["channel"] = flat // ch_per_board, flat % ch_per_board
     L = int(records["event_length"][0]) if len(records) else 0
     n_samples = int(pool.size)
     gen_s = time.perf_counter() - t0
@@ -364,7 +373,8 @@ def rank_main(args: argparse.Namespace) -> int:
                 "samples_per_gpu": n_samples,
                 "records_per_gpu": len(records),
                 "hits_per_gpu": int(n_hits),
-                "parallelism": f"channel-sharded x{n_gpus}, no data-path collective",
+                "parallelism": f"channel-sharded x{n_gpus} (each rank its slice of the preset's channels), no data-path "
+                               "collective; hit rows gathered over RCCL for event grouping",
             },
             "roofline": {
                 "bound": "hbm",
