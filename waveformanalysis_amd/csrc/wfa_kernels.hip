@@ -1968,7 +1968,10 @@ __global__ __launch_bounds__(128) void k_waveform_width(PoolView pool, int64_t n
 constexpr int kPeakBlock = 128;
 constexpr int kPeakErrEmptyWindow = 2;
 
-template <int SRC>
+// MODE >= 0 fixes the form of the detection value at compile time (the kernels that walk a lot dispatch on it once per
+// launch: the tests inside det_of were most of their scalar instruction stream); -1 = decided per call.
+//   0 records, derivative   1 records, plain   2 rows, plain   3 rows, derivative in float64   4 rows, derivative in float32
+template <int SRC, int MODE = -1>
 struct SignalAt {
     const uint16_t* xu;
     const float* xf;
@@ -1988,7 +1991,24 @@ struct SignalAt {
         return (double)(positive ? d : -d);  // signal = -normalized
     }
     // value k of the detection signal from the float32 samples w0 = w[k], w1 = w[k + 1]  (peak_finding.py:490-510)
+    __device__ __forceinline__ int deriv() const {
+        if constexpr (MODE >= 0) return MODE == 0 || MODE == 3 || MODE == 4;
+        else return use_derivative;
+    }
     __device__ __forceinline__ double det_of(float w0, float w1) const {
+        if constexpr (MODE == 0 || MODE == 1) {
+            const float d0 = w0 - b32;
+            const double s0 = (double)(positive ? d0 : -d0);
+            if constexpr (MODE == 1) return s0 - 0.0;
+            const float d1 = w1 - b32;
+            return (double)(positive ? d1 : -d1) - s0;
+        } else if constexpr (MODE == 2) {
+            return b64 - (double)w0;
+        } else if constexpr (MODE == 3) {
+            return -((double)w1 - (double)w0);
+        } else if constexpr (MODE == 4) {
+            return (double)(-(w1 - w0));
+        }
         if (rows) {
             if (!use_derivative) return b64 - (double)w0;                   // np.float64 baseline - row
             // -np.diff(int16 row) is exact; the streaming detector converts the row to float64 first
@@ -2003,7 +2023,7 @@ struct SignalAt {
     }
     __device__ __forceinline__ float wave(int i) const { return SRC == WFA_SRC_RAW ? (float)xu[i] : xf[i]; }
     __device__ __forceinline__ double det(int i) const {
-        return det_of(wave(i), use_derivative ? wave(i + 1) : 0.f);
+        return det_of(wave(i), deriv() ? wave(i + 1) : 0.f);
     }
     __device__ __forceinline__ void bind(const PoolView& pool, const RecView& rec, int64_t r, const PeakParams& pp) {
         const int64_t off = rec.off[r];
@@ -2021,14 +2041,21 @@ struct SignalAt {
     }
 };
 
+template <int SRC>
+__device__ __host__ inline int signal_mode(int rows, int use_derivative) {
+    if (!rows) return use_derivative ? 0 : 1;
+    if (!use_derivative) return 2;
+    return (SRC == WFA_SRC_RAW || rows == WFA_PEAK_SIGNAL_ROWS_F64) ? 3 : 4;
+}
+
 // det(i) for i = i_start, i_start + DIR, ... while the visitor returns true and i stays in [0, n).  The samples come
 // in aligned 16-byte chunks (8 uint16, or 2 x 4 float32) and are consumed from registers with static indices: the walks
 // below are pointer chases of up to a whole record per candidate, and with one load per step each step waited for a
 // cache line (5.1 ms per 10^9 samples for k_peak_eval; chunked: see DESIGN.md).  A derivative value needs the sample
 // after it, which is carried from the previous step (DIR < 0) or makes the value one step late (DIR > 0).
-template <int SRC, int DIR, typename F>
-__device__ __forceinline__ void stream_det(const SignalAt<SRC>& S, int i_start, const F& visit) {
-    const int deriv = S.use_derivative;
+template <int SRC, int DIR, typename SigT, typename F>
+__device__ __forceinline__ void stream_det(const SigT& S, int i_start, const F& visit) {
+    const int deriv = S.deriv();
     // sample index range this walk reads, in walking order
     const int k0 = DIR > 0 ? i_start : i_start + deriv;
     if (k0 < 0 || k0 >= S.L) return;
@@ -2065,8 +2092,8 @@ __device__ __forceinline__ void stream_det(const SignalAt<SRC>& S, int i_start, 
 
 // prominence + width of one candidate; false when it fails `prominence` or `width`
 // (scipy _peak_prominences / _peak_widths with wlen = None, rel_height = 0.5)
-template <int SRC>
-__device__ bool peak_passes(const SignalAt<SRC>& S, int peak, const PeakParams& pp, double& left_ip, double& right_ip) {
+template <int SRC, typename SigT>
+__device__ bool peak_passes(const SigT& S, int peak, const PeakParams& pp, double& left_ip, double& right_ip) {
     const double xp = S.det(peak);
     int left_base = peak, right_base = peak;
     double left_min = xp, right_min = xp;
@@ -2528,9 +2555,18 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_eval(PoolView pool, RecView
     int ok = 0;
     double l_ip = 0.0, r_ip = 0.0;
     if (!state || state[k]) {
-        SignalAt<SRC> S;
-        S.bind(pool, rec, cand_rec[k], pp);
-        ok = peak_passes(S, cand_pos[k], pp, l_ip, r_ip) ? 1 : 0;
+        auto run = [&](auto mode_tag) __attribute__((always_inline)) {
+            SignalAt<SRC, decltype(mode_tag)::value> S;
+            S.bind(pool, rec, cand_rec[k], pp);
+            ok = peak_passes<SRC>(S, cand_pos[k], pp, l_ip, r_ip) ? 1 : 0;
+        };
+        switch (signal_mode<SRC>(pp.rows, pp.use_derivative)) {  // wave-uniform: one form of det_of per launch
+            case 0: run(std::integral_constant<int, 0>{}); break;
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            default: run(std::integral_constant<int, 4>{}); break;
+        }
     }
     accept[k] = ok;
     ips[2 * k] = l_ip;
