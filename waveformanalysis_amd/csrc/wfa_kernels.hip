@@ -2189,8 +2189,8 @@ __device__ void write_peak_row(const SignalAt<SRC>& S, const RecView& rec, int64
 }
 
 // Streaming _local_maxima_1d + height + threshold; calls on_peak(position, value) per candidate in order.
-template <int SRC, typename F>
-__device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalAt<SRC>& S, const PeakParams& pp,
+template <int SRC, typename SigT, typename F>
+__device__ void scan_candidates(const PoolView& pool, int64_t off, const SigT& S, const PeakParams& pp,
                                 const F& on_peak) {
     const int n = S.n;
     if (n < 3) return;
@@ -2229,7 +2229,7 @@ __device__ void scan_candidates(const PoolView& pool, int64_t off, const SignalA
         for (int jj = 0; jj < 8; ++jj) {
             const int k = kb + jj;  // sample index in the record
             if (k < 0 || k >= L) continue;
-            if (S.use_derivative) {
+            if (S.deriv()) {
                 if (k >= 1) step(k - 1, S.det_of(w_prev, wf[jj]));
                 w_prev = wf[jj];
             } else {
@@ -2265,19 +2265,28 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks(PoolView pool, RecVie
                                                            int64_t* __restrict__ cand_rec) {
     const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (r >= rec.R) return;
-    SignalAt<SRC> S;
-    S.bind(pool, rec, r, pp);
     int n_out = 0;
-    if (S.L > 0) {
-        const int64_t base = FILL ? out_start[r] : 0;
-        scan_candidates(pool, rec.off[r], S, pp, [&](int peak, double val) {
-            if (FILL) {
-                cand_pos[base + n_out] = peak;
-                cand_val[base + n_out] = val;
-                cand_rec[base + n_out] = r;
-            }
-            ++n_out;
-        });
+    auto run = [&](auto mode_tag) __attribute__((always_inline)) {
+        SignalAt<SRC, decltype(mode_tag)::value> S;
+        S.bind(pool, rec, r, pp);
+        if (S.L > 0) {
+            const int64_t base = FILL ? out_start[r] : 0;
+            scan_candidates<SRC>(pool, rec.off[r], S, pp, [&](int peak, double val) {
+                if (FILL) {
+                    cand_pos[base + n_out] = peak;
+                    cand_val[base + n_out] = val;
+                    cand_rec[base + n_out] = r;
+                }
+                ++n_out;
+            });
+        }
+    };
+    switch (signal_mode<SRC>(pp.rows, pp.use_derivative)) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        default: run(std::integral_constant<int, 4>{}); break;
     }
     if (!FILL) counts[r] = n_out;
 }
@@ -2292,18 +2301,27 @@ __global__ __launch_bounds__(kPeakBlock) void k_find_peaks_slots(PoolView pool, 
                                                                  double* __restrict__ slot_val, int* __restrict__ overflow) {
     const int64_t r = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (r >= rec.R) return;
-    SignalAt<SRC> S;
-    S.bind(pool, rec, r, pp);
     int n_out = 0;
-    if (S.L > 0) {
-        const int64_t base = r * K;
-        scan_candidates(pool, rec.off[r], S, pp, [&](int peak, double val) {
-            if (n_out < K) {
-                slot_pos[base + n_out] = peak;
-                slot_val[base + n_out] = val;
-            }
-            ++n_out;
-        });
+    auto run = [&](auto mode_tag) __attribute__((always_inline)) {
+        SignalAt<SRC, decltype(mode_tag)::value> S;
+        S.bind(pool, rec, r, pp);
+        if (S.L > 0) {
+            const int64_t base = r * K;
+            scan_candidates<SRC>(pool, rec.off[r], S, pp, [&](int peak, double val) {
+                if (n_out < K) {
+                    slot_pos[base + n_out] = peak;
+                    slot_val[base + n_out] = val;
+                }
+                ++n_out;
+            });
+        }
+    };
+    switch (signal_mode<SRC>(pp.rows, pp.use_derivative)) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        default: run(std::integral_constant<int, 4>{}); break;
     }
     counts[r] = n_out;
     if (n_out > K) atomicOr(overflow, 1);
