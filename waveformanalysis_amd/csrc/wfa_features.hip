@@ -457,23 +457,32 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
             const fw_u4* rc = reinterpret_cast<const fw_u4*>(mine);
             fw_us2 dacc = {0, 0};
             uint32_t prev = cb > 0 && cb < CH ? reinterpret_cast<const uint32_t*>(mine)[cb * 4 - 1] : (uint32_t)mine[0] << 16;
+            auto diff_chunk = [&](int t, const fw_u4& v) __attribute__((always_inline)) {
+                fw_us2 cacc = {0, 0};
 #pragma unroll
-            for (int t = 0; t < kFwMaxChunks; ++t) {
-                if (t < cpl) {  // wave-uniform
-                    const int c = cb + t < CH ? cb + t : CH - 1;
-                    const fw_u4 v = rc[c];
-                    fw_us2 cacc = {0, 0};
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t di = v[i];  // (a bit_cast straight from the vector element reads element 0)
+                    const uint32_t sh = __builtin_amdgcn_alignbit(di, prev, 16);  // the same samples, one place earlier
+                    const fw_us2 cur = __builtin_bit_cast(fw_us2, di), old = __builtin_bit_cast(fw_us2, sh);
+                    const fw_us2 df = __builtin_elementwise_max(cur, old) - __builtin_elementwise_min(cur, old);
+                    cacc = __builtin_elementwise_max(cacc, df);
+                    prev = di;
+                }
+                const uint32_t keep = cb + t < ce ? __builtin_bit_cast(uint32_t, cacc) : 0u;
+                dacc = __builtin_elementwise_max(dacc, __builtin_bit_cast(fw_us2, keep));
+            };
+            auto chunk_at = [&](int t) { return rc[cb + t < CH ? cb + t : CH - 1]; };
+            // four chunks at a time while the lanes have that many (wave-uniform test once per four: their LDS reads are
+            // in flight together; a test per chunk left 13 dependent LDS round trips here), then the rest one by one
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t di = v[i];  // (a bit_cast straight from the vector element reads element 0)
-                        const uint32_t sh = __builtin_amdgcn_alignbit(di, prev, 16);  // the same samples, one place earlier
-                        const fw_us2 cur = __builtin_bit_cast(fw_us2, di), old = __builtin_bit_cast(fw_us2, sh);
-                        const fw_us2 df = __builtin_elementwise_max(cur, old) - __builtin_elementwise_min(cur, old);
-                        cacc = __builtin_elementwise_max(cacc, df);
-                        prev = di;
-                    }
-                    const uint32_t keep = cb + t < ce ? __builtin_bit_cast(uint32_t, cacc) : 0u;
-                    dacc = __builtin_elementwise_max(dacc, __builtin_bit_cast(fw_us2, keep));
+            for (int t0 = 0; t0 < kFwMaxChunks; t0 += 4) {
+                if (t0 + 4 <= cpl) {
+                    const fw_u4 v0 = chunk_at(t0), v1 = chunk_at(t0 + 1), v2 = chunk_at(t0 + 2), v3 = chunk_at(t0 + 3);
+                    diff_chunk(t0, v0); diff_chunk(t0 + 1, v1); diff_chunk(t0 + 2, v2); diff_chunk(t0 + 3, v3);
+                } else {
+#pragma unroll
+                    for (int t = t0; t < t0 + 4; ++t)
+                        if (t < cpl) diff_chunk(t, chunk_at(t));
                 }
             }
             int dmax = dacc.x > dacc.y ? dacc.x : dacc.y;
