@@ -38,7 +38,9 @@ extern "C" {
 #define WFA_E_LIMIT (-6)     /* record longer than WFA_MAX_RECORD_SAMPLES etc. */
 
 /* The plain threshold kernel keeps a record's hit bitmap in LDS (one 64-bit word per 64 samples, 4 waves per block,
- * 64 KiB): 2038 words.  Everything else indexes samples with 32-bit integers and sums them in 64 bits. */
+ * 64 KiB): 2038 words.  The streaming hit kernel (k_sg_runs32) packs a run edge as (record << 16) | sample and is only
+ * chosen for uniform records of at most 65 504 samples; longer uniform records take the bitmap route.  Everything else
+ * indexes samples with 32-bit integers and sums them in 64 bits. */
 #define WFA_MAX_RECORD_SAMPLES 130432
 #define WFA_MAX_SG_WINDOW 63
 
@@ -329,6 +331,11 @@ int wfa_rccl_allgather_counts(wfa_ctx* ctx, int64_t n_rows, int64_t* counts);
  * (row_bytes must be 60) without a host round trip.  counts = result of step 1. */
 int wfa_rccl_gather_rows(wfa_ctx* ctx, const void* rows, int64_t n_rows, int32_t row_bytes,
                          int root, const int64_t* counts, void* out);
+/* on != 0: the 60-byte rows of the following exchanges are appended on the root behind the rows already gathered (a rank
+ * that works through several shards or time-range chunks sends one exchange per chunk; event grouping,
+ * event_grouping.py:286-471, then reads one table: wfa_hit_rows_source(ctx, 2)).  `out` of such an exchange receives
+ * only that exchange's rows.  on == 0: back to one table per exchange; the gathered table is dropped. */
+int wfa_rccl_gather_append(wfa_ctx* ctx, int on);
 int wfa_rccl_destroy(wfa_ctx* ctx);
 
 #ifdef __cplusplus

@@ -1,0 +1,136 @@
+"""Where the streaming kernel k_sg_runs32 must hand over to the general (bitmap) route, and that it does so without
+losing or corrupting a hit (reference: hit_finder.py:329-413, the runs of `sig >= thr` per record):
+
+* its run events are (record in span << 16) | sample: uniform records whose stride does not fit 16 bits are not
+  taken at all (the build before refused nothing above L = 64 and silently mis-sorted events from L = 65 536 on);
+* a span buffers 1024 events per wave in LDS: a span with more raises flag 1, the pass is redone on the bitmap route
+  for this upload, and the next upload tries the streaming kernel again.  (Flag 2 -- the patched events of a span
+  outgrow its 2048-event slot -- needs more than 1024 + 64 * 2 * (H + 1) events and is unreachable for W <= 11.)
+"""
+
+import numpy as np
+import pytest
+
+from oracle import wfa_oracle as O
+from tests import golden_util as G
+from waveformanalysis_amd import _lib, synth
+from waveformanalysis_amd.device import DeviceSession
+from waveformanalysis_amd.dtypes import RECORDS_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def uniform_long_run(n_rec, L, seed):
+    rng = np.random.default_rng(seed)
+    ped = rng.integers(7800, 8200, size=n_rec)
+    w = ped[:, None] + np.rint(rng.normal(0, 3, (n_rec, L)))
+    t = np.arange(400)
+    for r in range(n_rec):
+        starts = rng.integers(60, L - 520, size=max(1, L // 6000))
+        for t0 in starts:
+            amp = 10 ** rng.uniform(1.3, 3.3)
+            w[r, t0:t0 + 400] -= amp * (np.exp(-t / rng.uniform(10, 60)) - np.exp(-t / 4.0))
+        if r % 3 == 0:                                    # pulses on both record edges: head / tail events
+            w[r, :30] -= 200.0 * np.exp(-np.arange(30) / 12.0)
+            w[r, L - 25:] -= 150.0
+    pool = np.clip(w, 0, 16383).astype(np.uint16)
+    rec = np.zeros(n_rec, dtype=RECORDS_DTYPE)
+    rec["wave_offset"] = np.arange(n_rec, dtype=np.int64) * L
+    rec["event_length"] = L
+    rec["baseline"] = pool[:, :40].astype(np.float64).mean(axis=1)
+    rec["timestamp"] = 10**12 + np.arange(n_rec, dtype=np.int64) * 10**9
+    rec["dt"], rec["board"], rec["channel"] = 4, 0, np.arange(n_rec) % 16
+    rec["record_id"] = np.arange(n_rec)
+    rec["polarity"] = "unknown"
+    return rec, pool.reshape(-1)
+
+
+@pytest.mark.parametrize("L", [65_504, 65_536, 70_016])
+@pytest.mark.parametrize("fused_baseline", [False, True])
+def test_uniform_records_around_the_16_bit_event_limit(L, fused_baseline):
+    """128 back-to-back records of L samples (L % 32 == 0: the layout the streaming kernel takes).  65 504 is its
+    largest stride; the two longer ones must come out of the bitmap route -- same rows as the oracle either way, and
+    the same rows as with the streaming kernel switched off."""
+    n_rec = 128 if L <= 65_536 else 96
+    rec, pool = uniform_long_run(n_rec, L, seed=L)
+    want = O.threshold_hits_chunked(rec, O.filter_wave_pool(rec, pool))
+    assert len(want) > 500
+    assert np.any(want["edge_end"] == L) and np.any(want["edge_start"] == 0)
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        up = rec.copy()
+        if fused_baseline:
+            up["baseline"] = np.nan
+        sess.upload_records(up, 10.0)
+        sess.profile(True)
+        run = (lambda: sess.fused_baseline_filter_hits((0, 40), 2, 2)) if fused_baseline else \
+            (lambda: sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2))
+        got = run()
+        names = sess.profile_report()
+        streamed = any(k.startswith("k_sg_runs32") for k in names)
+        assert streamed == (L <= 65_504), sorted(names)
+        G.assert_struct_equal(got, want, float_rtol=1e-6, what=f"uniform L={L}")
+        sess.set_option("no_runs32", True)
+        sess.upload_records(up, 10.0)
+        G.assert_struct_equal(run(), got, what=f"uniform L={L}: bitmap route == default route")
+
+
+def test_event_overflow_of_a_span_falls_back_and_recovers():
+    """thr = 1.0 on sigma = 3 noise: ~4000 runs per 64-record span, four times what a wave buffers."""
+    rec, pool = synth.make_run(640, "v1725", cfg=5)
+    filt = O.filter_wave_pool(rec, pool)
+    want_low = O.threshold_hits_chunked(rec, filt, threshold=1.0)
+    per_span = np.bincount(np.searchsorted(rec["record_id"], want_low["record_id"]) // 64, minlength=10)
+    assert per_span.min() > 1024, per_span   # > 512 hits = 1024 events in every span
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        sess.upload_records(rec, 1.0)
+        sess.profile(True)
+        got = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
+        first = sess.profile_report()
+        # the streaming kernel ran, raised the overflow flag, and the bitmap route produced the rows
+        assert first.get("k_sg_runs32", (0, 0))[1] == 1, sorted(first)
+        assert any(k.startswith("k_sg_mask") for k in first) and "k_hit_runs" in first, sorted(first)
+        G.assert_struct_equal(got, want_low, float_rtol=1e-6, what="overflowing spans")
+        # same upload, second pass: straight to the bitmap route (the flag is remembered per upload)
+        sess.profile(True)
+        G.assert_struct_equal(sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2), got, what="second pass after overflow")
+        assert "k_sg_runs32" not in sess.profile_report()
+        # fused baseline variant overflows the same way
+        blank = rec.copy()
+        blank["baseline"] = np.nan
+        sess.upload_records(blank, 1.0)
+        sess.profile(True)
+        got_bl = sess.fused_baseline_filter_hits((0, 40), 2, 2)
+        assert sess.profile_report().get("k_sg_runs32<baseline>", (0, 0))[1] == 1
+        G.assert_struct_equal(got_bl, want_low, float_rtol=1e-6, what="overflowing spans, fused baseline")
+        # the next upload takes the streaming kernel again
+        sess.upload_records(rec, 10.0)
+        sess.profile(True)
+        got_hi = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
+        again = sess.profile_report()
+        assert "k_sg_runs32" in again and not any(k.startswith("k_sg_mask") for k in again), sorted(again)
+        G.assert_struct_equal(got_hi, O.threshold_hits_chunked(rec, filt), float_rtol=1e-6, what="after recovery")
+
+
+def test_one_busy_span_among_quiet_ones():
+    """Only span 3 overflows (its records carry a square wave around the threshold): the whole upload is redone on the
+    bitmap route and still equals the oracle."""
+    rec, pool = synth.make_run(512, "v1725", cfg=6)
+    pool = pool.copy()
+    w = pool.reshape(512, 800)
+    sq = (np.arange(800) // 6 % 2).astype(np.int64) * 40
+    w[192:256] = np.clip(w[192:256].astype(np.int64) - sq[None, :], 0, 16383).astype(np.uint16)
+    rec["baseline"] = w[:, :40].astype(np.float64).mean(axis=1)
+    want = O.threshold_hits_chunked(rec, O.filter_wave_pool(rec, pool))
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        sess.upload_records(rec, 10.0)
+        sess.profile(True)
+        got = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
+        names = sess.profile_report()
+        assert "k_sg_runs32" in names and "k_hit_runs" in names, sorted(names)
+        G.assert_struct_equal(got, want, float_rtol=1e-6, what="one overflowing span")

@@ -76,6 +76,7 @@ SIGNATURES = {
     "wfa_rccl_init": (_int, [_p, _int, _int, _p]),
     "wfa_rccl_allgather_counts": (_int, [_p, _i64, _p]),
     "wfa_rccl_gather_rows": (_int, [_p, _p, _i64, _i32, _int, _p, _p]),
+    "wfa_rccl_gather_append": (_int, [_p, _int]),
     "wfa_rccl_destroy": (_int, [_p]),
 }
 

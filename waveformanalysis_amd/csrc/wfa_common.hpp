@@ -145,6 +145,7 @@ struct wfa_ctx {
     int ht_src = 1;            // wfa_hit_rows_source: 1 = rows of the last hit pass, 2 = rows of the last gather
     wfa::DevBuf gathered;      // rows the last wfa_rccl_gather_rows left on the root
     int64_t gathered_n = -1;
+    bool gather_append = false;  // wfa_rccl_gather_append: exchanges add to the gathered table instead of replacing it
     int64_t ht_n = -1, ht_groups = 0;
     int ht_kind = 0;  // 1 = event grouping, 2 = hit merge
     int64_t* ht_perm = nullptr;

@@ -7,6 +7,8 @@
 
 #include <rccl/rccl.h>
 
+#include <utility>
+
 #include "wfa_common.hpp"
 
 using namespace wfa;
@@ -73,6 +75,13 @@ int wfa_rccl_allgather_counts(wfa_ctx* c, int64_t n_rows, int64_t* counts) {
     return WFA_OK;
 }
 
+int wfa_rccl_gather_append(wfa_ctx* c, int on) {
+    if (!c) return fail(WFA_E_INVALID, "null context");
+    c->gather_append = on != 0;
+    if (!on) c->gathered_n = -1;  // the next exchange starts a new table
+    return WFA_OK;
+}
+
 int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t row_bytes, int root,
                          const int64_t* counts, void* out) {
     if (!c || !c->comm) return fail(WFA_E_STATE, "RCCL communicator not initialised");
@@ -87,6 +96,8 @@ int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t r
     const uint8_t* d_rows = nullptr;
     DevBuf staged;
     DevBuf& d_all = c->gathered;  // stays resident on the root: the hit-table stages read it (wfa_hit_rows_source(ctx, 2))
+    // append mode (wfa_rccl_gather_append): the rows of this exchange go behind the 60-byte rows earlier exchanges left
+    const int64_t base = (c->gather_append && row_bytes == 60 && c->gathered_n > 0) ? c->gathered_n : 0;
     c->gathered_n = -1;
     int rc = WFA_OK;
     if (rows == nullptr) {
@@ -103,13 +114,25 @@ int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t r
     int64_t total = 0;
     for (int r = 0; r < n; ++r) total += counts[r];
     if (c->rank == root) {
-        if ((rc = d_all.ensure((size_t)total * row_bytes + 64))) { staged.release(); return rc; }
+        const size_t want = (size_t)(base + total) * row_bytes + 64;
+        if (base > 0 && d_all.cap < want) {  // grow without losing the rows already gathered
+            DevBuf bigger;
+            if ((rc = bigger.ensure(want + want / 2))) { staged.release(); return rc; }
+            hipError_t ce = hipMemcpyAsync(bigger.ptr, d_all.ptr, (size_t)base * row_bytes, hipMemcpyDeviceToDevice, c->stream);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+            if (ce != hipSuccess) { staged.release(); return fail(WFA_E_HIP, "gather buffer growth failed: %s", hipGetErrorString(ce)); }
+            std::swap(d_all.ptr, bigger.ptr);
+            std::swap(d_all.cap, bigger.cap);
+        } else if ((rc = d_all.ensure(want))) {
+            staged.release();
+            return rc;
+        }
     }
     ncclResult_t nr = ncclGroupStart();
     if (nr == ncclSuccess && n_rows > 0)
         nr = ncclSend(d_rows, (size_t)n_rows * row_bytes, ncclUint8, root, comm, c->stream);
     if (c->rank == root) {
-        int64_t at = 0;
+        int64_t at = base;
         for (int r = 0; r < n && nr == ncclSuccess; ++r) {
             if (counts[r] > 0)
                 nr = ncclRecv(d_all.as<uint8_t>() + at * row_bytes, (size_t)counts[r] * row_bytes, ncclUint8, r,
@@ -121,11 +144,12 @@ int wfa_rccl_gather_rows(wfa_ctx* c, const void* rows, int64_t n_rows, int32_t r
     if (nr == ncclSuccess) nr = ge;
     hipError_t e = hipSuccess;
     if (nr == ncclSuccess && c->rank == root && total > 0 && out)  // out == NULL: the rows are only wanted on the device
-        e = hipMemcpyAsync(out, d_all.ptr, (size_t)total * row_bytes, hipMemcpyDeviceToHost, c->stream);
+        e = hipMemcpyAsync(out, d_all.as<uint8_t>() + (size_t)base * row_bytes, (size_t)total * row_bytes,
+                           hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = e2;
     staged.release();
-    if (nr == ncclSuccess && e == hipSuccess && c->rank == root && row_bytes == 60) c->gathered_n = total;
+    if (nr == ncclSuccess && e == hipSuccess && c->rank == root && row_bytes == 60) c->gathered_n = base + total;
     if (nr != ncclSuccess) return fail(WFA_E_RCCL, "row gather failed: %s", ncclGetErrorString(nr));
     if (e != hipSuccess) return fail(WFA_E_HIP, "row gather failed: %s", hipGetErrorString(e));
     return WFA_OK;

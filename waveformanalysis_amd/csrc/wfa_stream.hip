@@ -34,6 +34,7 @@ constexpr int kSpl = 32;                  // samples per lane per tile
 constexpr int kTileSamples = kWave * kSpl;  // 2048
 constexpr int kEvCap = 1024;   // events buffered per span and wave (typical span: ~220)
 constexpr int kEvSlot = 2048;  // events a span may write: kEvCap + the 2 (H + 1) an edge patch can add per record
+constexpr int kMaxEventPos = 65504;  // largest record stride whose positions (0 .. S) fit the 16-bit field of an event
 
 typedef unsigned short wfa_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int wfa_v4u __attribute__((ext_vector_type(4)));
@@ -581,6 +582,9 @@ int64_t sg_runs32_event_slot() { return kEvSlot; }
 bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl) {
     if (!sg.int_ok || sg.W < 5 || sg.W > 11 || !(sg.W & 1)) return false;
     if (S % kSpl != 0 || S - L < 0 || S - L >= kSpl || L < 64) return false;
+    // run events are (record in span << 16) | position, and the tail event of a record sits at position L: every
+    // position up to S must fit 16 bits.  Longer uniform records take the bitmap route (32-bit sample indices).
+    if (S > kMaxEventPos) return false;
     if (S != L && (kSpl - (S - L)) < sg.W / 2) return false;  // the last lane of a record holds its H edge samples
     if (fused_bl && !(bl_start == 0 && bl_end == 40)) return false;
     return true;

@@ -514,6 +514,11 @@ class DeviceSession:
         _lib.check(self._lib.wfa_rccl_init(self._h, int(rank), int(n_ranks), buf))
         self.rank, self.n_ranks = int(rank), int(n_ranks)
 
+    def rccl_gather_append(self, on: bool = True) -> None:
+        """on: the following gathers append their rows on the root behind those already there (one exchange per shard
+        or time-range chunk, one table for event grouping); off: one table per gather again, the table is dropped."""
+        _lib.check(self._lib.wfa_rccl_gather_append(self._h, int(bool(on))))
+
     def rccl_gather_rows(self, rows: np.ndarray | None, n_rows: int, row_dtype: np.dtype, root: int = 0,
                          download: bool = True):
         """Gather structured rows from all ranks to `root` (rank order).  rows=None sends the
