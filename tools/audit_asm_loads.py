@@ -19,12 +19,12 @@ def regs_of(text: str) -> set:
     return out
 
 
-def main(path: str) -> int:
+def main(path: str, prefix: str = r"_ZN3wfa11k_sg_runs32") -> int:
     txt = open(path).read()
     bad = 0
     n_kernels = 0
-    for fn in re.split(r"\n(?=_ZN3wfa\w+:)", txt):
-        if not fn.startswith("_ZN3wfa11k_sg_runs32"):
+    for fn in re.split(r"\n(?=_Z\w+:)", txt):
+        if not re.match(prefix, fn):
             continue
         n_kernels += 1
         name = fn.split(":")[0]
@@ -52,7 +52,11 @@ def main(path: str) -> int:
                     while k < len(lines):
                         ln = lines[k].strip()
                         if ";;#ASMSTART" in ln and "s_waitcnt vmcnt" in lines[k + 1]:
-                            break
+                            # a wait that lists its registers (as an assembly comment) only ends the walk when it names
+                            # this issue's registers: with two tiles in flight the next wait is the other tile's
+                            named = regs_of(lines[k + 1].split(";", 1)[1]) if ";" in lines[k + 1] else dst
+                            if named & dst:
+                                break
                         if ";;#ASMSTART" in ln and any("buffer_load_dwordx4" in x for x in lines[k + 1:k + 8]):
                             # the other tile's issue: its registers must be disjoint
                             other = set()
@@ -70,11 +74,11 @@ def main(path: str) -> int:
                 i = j
             i += 1
     if n_kernels == 0:
-        print("no k_sg_runs32 kernel found in", path)
+        print("no kernel matching", prefix, "found in", path)
         return 1
     print(f"audit_asm_loads: {n_kernels} kernels checked, {bad} problems")
     return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(main(*sys.argv[1:3]))
