@@ -93,9 +93,10 @@ __device__ __forceinline__ void wait_all(TileM& d) {
                  : "memory");
 }
 
-template <bool STORE, bool EARLY, int MAP>
+template <int STORE, bool EARLY, int MAP>
 __global__ __launch_bounds__(256, 3) void k_mfma(Args a) {
     __shared__ __attribute__((aligned(16))) uint32_t xs[4][64];
+    __shared__ uint32_t sink[STORE == 2 ? 4 * 1664 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t span = (int64_t)blockIdx.x * 4 + wv;
     if (span >= a.n_spans) return;
@@ -183,7 +184,9 @@ __global__ __launch_bounds__(256, 3) void k_mfma(Args a) {
         uint32_t bits = 0;
 #pragma unroll
         for (int gs = 0; gs < 4; ++gs) bits |= __builtin_amdgcn_alignbit(xv[gs], xv[gs], rot[gs]) & msk[gs];
-        if (STORE) {
+        if (STORE == 2) {
+            sink[wv * 1664 + t * 64 + lane] = bits;  // the real kernel's shape: the word goes to LDS, the span's flush reads it
+        } else if (STORE) {
             if (t < T) a.bits[(span * T + t) * 64 + lane] = bits;
         } else {
             const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)(carry << 31), (int)bits, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -210,6 +213,12 @@ __global__ __launch_bounds__(256, 3) void k_mfma(Args a) {
     }
     wait_all(ta);
     wait_all(tb);
+    if (STORE == 2) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t w = 0;
+        for (int k = 0; k < 25; ++k) w ^= sink[wv * 1664 + lane * 25 + k];  // lane = record: its 25 words
+        if (w == 0x12345678u) atomicAdd(a.count, 1ull);
+    }
     if (!STORE) {
         for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
         if (lane == 0) atomicAdd(a.count, cnt);
@@ -301,8 +310,9 @@ __device__ __forceinline__ uint32_t from_next(uint32_t last, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
 }
 
-template <bool STORE, bool EARLY, bool BAND>
+template <int STORE, bool EARLY, bool BAND>
 __global__ __launch_bounds__(256, 3) void k_dot2(Args a) {
+    __shared__ uint32_t sink[STORE == 2 ? 4 * 1664 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t span = (int64_t)blockIdx.x * 4 + wv;
     if (span >= a.n_spans) return;
@@ -361,7 +371,9 @@ __global__ __launch_bounds__(256, 3) void k_dot2(Args a) {
             if (BAND && __ballot(umax == 0x7fffffffu) != 0) hb ^= 1;  // keeps the band tracking of the real kernel alive
             bits |= (hb & 0xffffu) << (16 * h);
         }
-        if (STORE) {
+        if (STORE == 2) {
+            sink[wv * 1664 + t * 64 + lane] = bits;
+        } else if (STORE) {
             if (t < T) a.bits[(span * T + t) * 64 + lane] = bits;
         } else {
             const uint32_t prev = from_prev(carry << 31, bits);
@@ -390,6 +402,12 @@ __global__ __launch_bounds__(256, 3) void k_dot2(Args a) {
     }
     wait_all_d(tb);
     wait_all_d(ta);
+    if (STORE == 2) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t w = 0;
+        for (int k = 0; k < 25; ++k) w ^= sink[wv * 1664 + lane * 25 + k];
+        if (w == 0x12345678u) atomicAdd(a.count, 1ull);
+    }
     if (!STORE) {
         for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
         if (lane == 0) atomicAdd(a.count, cnt);
@@ -425,15 +443,14 @@ int main(int argc, char** argv) {
     // ---- correctness: every variant against the host on the first spans
     const int64_t check_spans = n_spans < 40 ? n_spans : 40;
     std::vector<uint32_t> got(words);
-    struct Variant { const char* name; void (*store)(Args); void (*count)(Args); };
+    struct Variant { const char* name; void (*store)(Args); void (*count)(Args); void (*lds)(Args); };
     const Variant variants[] = {
-        {"mfma", k_mfma<true, false, 0>, k_mfma<false, false, 0>},
-        {"mfma early", k_mfma<true, true, 0>, k_mfma<false, true, 0>},
-        {"mfma map1", k_mfma<true, false, 1>, k_mfma<false, false, 1>},
-        {"mfma map1 early", k_mfma<true, true, 1>, k_mfma<false, true, 1>},
-        {"dot2", k_dot2<true, false, true>, k_dot2<false, false, true>},
-        {"dot2 early", k_dot2<true, true, true>, k_dot2<false, true, true>},
-        {"dot2 early noband", k_dot2<true, true, false>, k_dot2<false, true, false>},
+        {"mfma", k_mfma<1, false, 0>, k_mfma<0, false, 0>, k_mfma<2, false, 0>},
+        {"mfma map1", k_mfma<1, false, 1>, k_mfma<0, false, 1>, k_mfma<2, false, 1>},
+        {"mfma map1 early", k_mfma<1, true, 1>, k_mfma<0, true, 1>, k_mfma<2, true, 1>},
+        {"dot2", k_dot2<1, false, true>, k_dot2<0, false, true>, k_dot2<2, false, true>},
+        {"dot2 noband", k_dot2<1, false, false>, k_dot2<0, false, false>, k_dot2<2, false, false>},
+        {"dot2 early noband", k_dot2<1, true, false>, k_dot2<0, true, false>, k_dot2<2, true, false>},
     };
     for (const Variant& v : variants) {
         a.bits = d_bits;
@@ -461,6 +478,7 @@ int main(int argc, char** argv) {
     for (const Variant& v : variants) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.store), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.count), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.lds), hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 1024));
     }
     {
         void (*pats[3])(Args) = {k_loads<0>, k_loads<1>, k_loads<2>};
@@ -479,16 +497,18 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep)
         for (const Variant& v : variants)
             for (int store = 0; store < 4; ++store) {
-                a.bits = (store & 1) ? d_bits : nullptr;
-                const unsigned dyn = (store & 2) ? 48 * 1024 : 0;
+                if (store == 0) continue;  // (free occupancy of the count variant: not informative)
+                a.bits = store == 1 ? d_bits : nullptr;
+                // 3 blocks per CU: 48 KiB of dynamic LDS, or 24 KiB next to the 26 KiB sink of the lds variant
+                const unsigned dyn = store == 1 ? 48 * 1024 : store == 2 ? 48 * 1024 : 24 * 1024;
                 CK(hipMemset(d_cnt, 0, 8));
-                auto launch = [&]() { hipLaunchKernelGGL((store & 1) ? v.store : v.count, dim3(grid), dim3(256), dyn, 0, a); };
+                auto launch = [&]() { hipLaunchKernelGGL(store == 1 ? v.store : store == 2 ? v.count : v.lds, dim3(grid), dim3(256), dyn, 0, a); };
                 launch();
                 CK(hipEventRecord(e0));
                 for (int i = 0; i < 10; ++i) launch();
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                printf("%-18s %-6s %-6s %.4f ms  %.2f TB/s\n", v.name, (store & 1) ? "store" : "count", dyn ? "occ3" : "free", ms / 10,
+                printf("%-18s %-6s %-6s %.4f ms  %.2f TB/s\n", v.name, store == 1 ? "store" : store == 2 ? "count" : "lds", "occ3", ms / 10,
                        (double)N * 2 / (ms / 10 * 1e-3) / 1e12);
             }
     return 0;

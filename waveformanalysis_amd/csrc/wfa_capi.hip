@@ -207,7 +207,8 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
     if (!sg_runs32_supported(sp0, sp.L, sp.S, bl_start, bl_end, fused_bl)) return WFA_OK;
     int rc;
     const int64_t R = c->R;
-    sp.rs = 64;
+    int32_t g_wstride = 0, g_nseg = 0, g_segw = 0;
+    sg_runs32_geometry(sp.S, &sp.rs, &g_wstride, &g_nseg, &g_segw);
     sp.n_spans = (R + sp.rs - 1) / sp.rs;
     const int64_t ns = sp.n_spans;
     const int64_t nb = scan_blocks_for(ns);
@@ -256,10 +257,8 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         // sg_plan.py: guard = 8 eps den^2 2^24 + 1 with eps = bound on |scipy's float64 chain - exact rational|; here in
         // numerator units with a factor 4 of head room (and never below 1e-6)
         ra.delta = std::max(4.0 * (double)sp0.guard / (8.0 * (double)sp0.den * 16777216.0), 1e-6);
-#ifdef WFA_MEASURE
-        ra.dbg = getenv("WFA_RUNS_DBG") ? atoi(getenv("WFA_RUNS_DBG")) : 0;  // results are NOT valid with it set
-#endif
         ra.W = sp0.W; ra.L = sp.L; ra.S = sp.S; ra.positive = sp.positive; ra.rs = sp.rs;
+        ra.wstride = g_wstride; ra.nseg = g_nseg; ra.segw = g_segw;
         ra.off0 = sp.off0; ra.n_spans = ns;
         ra.ev = rn.ev; ra.ev_cap = rn.ev_cap; ra.cursor = rn.cursor; ra.span_off = rn.span_off; ra.span_cnt = rn.span_cnt;
         ra.flags = rn.flags;

@@ -107,7 +107,8 @@ struct RunsArgs {
     int32_t den_edge, margin_edge;  // edge projection rows: denominator, band half-width
     double delta;           // numerator units by which scipy's float64 chain may differ from the exact rational
     int32_t W, L, S, positive, rs;
-    int32_t dbg;            // measurement knobs (WFA_MEASURE builds; 0 in production)
+    int32_t wstride, nseg, segw;  // sg_runs32_geometry: LDS words per record (odd), flush segments per record, words per segment
+    int32_t dbg;            // unused
     int64_t off0, n_spans;
     uint32_t* ev;
     int64_t ev_cap;
@@ -215,6 +216,7 @@ hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const Pool
                                  const SgParams& sg, const MaskParams& mp, const SpanParams& sp);
 bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl);
 int64_t sg_runs32_event_slot();  // events of the buffer every span owns
+void sg_runs32_geometry(int32_t S, int32_t* rs, int32_t* wstride, int32_t* nseg, int32_t* segw);
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a);
 hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,
                                const int64_t* span_row0, int64_t cap, int4* desc);
