@@ -134,3 +134,33 @@ def test_one_busy_span_among_quiet_ones():
         names = sess.profile_report()
         assert "k_sg_runs32" in names and "k_hit_runs" in names, sorted(names)
         G.assert_struct_equal(got, want, float_rtol=1e-6, what="one overflowing span")
+
+
+@pytest.mark.parametrize("preset,n", [("v1725", 6000), ("vx2730", 3000)])
+def test_flat_rows_kernel_equals_grouped_rows_kernel(preset, n):
+    """The chunk-per-lane row kernel (default) against the 8-lanes-per-hit kernel of rounds 1-2 (`rows_grouped`): same
+    extremum (float32 order, first index), same rows; the float64 window sums are added in another order (tolerance of
+    the float fields 1e-6, north_star), everything else is bit-identical.  Both against the oracle."""
+    rec, pool = synth.make_run(n, preset, cfg=31)
+    want = O.threshold_hits_chunked(rec, O.filter_wave_pool(rec, pool))
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        sess.upload_records(rec, 10.0)
+        sess.profile(True)
+        flat = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
+        assert "k_hit_rows_flat" in sess.profile_report()
+        sess.set_option("rows_grouped", True)
+        sess.profile(True)
+        grouped = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)
+        assert "k_hit_rows_grp" in sess.profile_report()
+        G.assert_struct_equal(flat, want, float_rtol=1e-6, what="flat rows vs oracle")
+        G.assert_struct_equal(grouped, want, float_rtol=1e-6, what="grouped rows vs oracle")
+        for name in flat.dtype.names:
+            if name != "integral":
+                np.testing.assert_array_equal(flat[name], grouped[name], err_msg=name)
+        # wide extensions: windows that reach both record edges and the zero padding
+        sess.set_option("rows_grouped", False)
+        wide = sess.threshold_hits(_lib.SRC_SG_FUSED, 900, 900)
+        G.assert_struct_equal(wide, O.threshold_hits_chunked(rec, O.filter_wave_pool(rec, pool), left_extension=900,
+                                                             right_extension=900), float_rtol=1e-6, what="wide windows")

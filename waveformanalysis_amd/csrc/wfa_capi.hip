@@ -295,8 +295,8 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
             {
                 LaunchTimer t(c);
                 WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pvf, rvf, sp0, rp, c->hit_desc.as<int4>(), n_rows,
-                                                   c->hit_out.as<uint8_t>()));
-                if (int r2 = t.end("k_hit_rows_grp")) return r2;
+                                                   c->hit_out.as<uint8_t>(), c->opt.rows_grouped));
+                if (int r2 = t.end(c->opt.rows_grouped ? "k_hit_rows_grp" : "k_hit_rows_flat")) return r2;
             }
             {
                 LaunchTimer t(c);
@@ -477,8 +477,8 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
             {
                 LaunchTimer t(c);
                 WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pvf, rvf, sp0, rp, c->hit_desc.as<int4>(), bound,
-                                                   c->hit_out.as<uint8_t>()));
-                if ((rc = t.end("k_hit_rows_grp"))) return rc;
+                                                   c->hit_out.as<uint8_t>(), c->opt.rows_grouped));
+                if ((rc = t.end(c->opt.rows_grouped ? "k_hit_rows_grp" : "k_hit_rows_flat"))) return rc;
             }
             {
                 LaunchTimer t(c);
@@ -521,8 +521,8 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
         {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_hit_rows_fast(c->stream, pvf, rvf, sp0, rp, c->hit_desc.as<int4>(), total,
-                                               c->hit_out.as<uint8_t>()));
-            if ((rc = t.end("k_hit_rows_grp"))) return rc;
+                                               c->hit_out.as<uint8_t>(), c->opt.rows_grouped));
+            if ((rc = t.end(c->opt.rows_grouped ? "k_hit_rows_grp" : "k_hit_rows_flat"))) return rc;
         }
         {
             LaunchTimer t(c);
@@ -690,6 +690,7 @@ int wfa_set_option(wfa_ctx* c, const char* name, int value) {
     else if (n == "no_runs32") c->opt.no_runs32 = v;
     else if (n == "no_speculate") c->opt.no_speculate = v;
     else if (n == "no_peak_slots") c->opt.no_peak_slots = v;
+    else if (n == "rows_grouped") c->opt.rows_grouped = v;
     else return fail(WFA_E_INVALID, "unknown option '%s'", name);
     return WFA_OK;
 }

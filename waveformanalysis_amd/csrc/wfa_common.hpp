@@ -121,6 +121,7 @@ struct wfa_ctx {
         bool no_runs32 = false;    // bitmap route (k_sg_mask_span16 + scan + k_hit_runs) instead of k_sg_runs32
         bool no_speculate = false; // exact row launches (host round trip for the hit count)
         bool no_peak_slots = false; // find_peaks: count + fill walks instead of one walk into per-record slots
+        bool rows_grouped = false;  // hit rows: the 8-lanes-per-hit kernel instead of the flat chunk-per-lane kernel
     } opt;
     wfa::RunsCold* h_cold = nullptr;   // pinned staging (lives behind h_total)
     wfa::RunsCold run_cold_host{};     // what the device copy holds

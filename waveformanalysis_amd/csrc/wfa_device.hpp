@@ -208,6 +208,19 @@ __device__ __forceinline__ int wave_sum_i32_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2,3
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int& total) {
+    // inclusive scan over the 64 lanes with DPP row shifts / broadcasts, returned as exclusive
+    int s = v;
+    s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, true);  // row_shr:1
+    s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, true);  // row_shr:2
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, true);  // row_shr:4
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, true);  // row_shr:8
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(s, 63);
+    return s - v;
+}
+
 __device__ __forceinline__ int clamp_to_i32(double v) {
     return v >= 2147483647.0 ? INT32_MAX : (v <= -2147483648.0 ? INT32_MIN : (int)v);
 }

@@ -1351,6 +1351,213 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
     }
 }
 
+// fast path, flat form (round 3): the window samples of 64 consecutive hits as ONE list of aligned 8-sample chunks, a chunk per
+// lane.  The grouped kernel above gives every hit 8 lanes and iterates as long as the longest hit of a wave: half of all
+// hits are fragments of a few samples that fill one or two of their 8 lanes, and it issued 4.4 x the instructions the
+// window samples need (profiles/r02_pmc_sq_counters.txt: 257.6e6 for 2.1e6 hits).  Here every wave works on its own 64
+// hits, one wave per workgroup, no block barriers (measured on the way: 64 hits per 256-thread block with phases separated
+// by __syncthreads spent 74 % of its wave cycles waiting, 0.60 ms; 16 hits per wave with 4 lanes per hit 0.46 ms, with the
+// next round's loads in flight 0.42 ms = the grouped kernel's time at 0.6 x its instructions, but 70 per hit of them
+// per-hit bookkeeping that 64 hits per wave divide by four):
+//   A  lane = hit: window, first chunk, chunk count; a prefix sum of the counts numbers the wave's chunks;
+//   B  lane = chunk: three 16-byte loads (own chunk + both neighbours), 8 exact numerators, float32-ordered first extremum
+//      and clamped float64 sum of its in-window samples -> one (key, sum) pair per chunk in LDS, key = (ordered float32,
+//      sample index): the 64-bit minimum is the reference's first maximum of the signal;
+//   C  lane = hit: walk its chunks' pairs in order (a fixed order: the row bytes do not depend on scheduling), add the
+//      <= 2H edge samples / zero padding literally, write the row.
+// A wave whose hits hold more than kFlatCap chunks runs B and C in batches.
+constexpr int kFlatHits = 64;   // per wave
+constexpr int kFlatCap = 512;   // chunks per batch and wave (8 KiB of pairs: 12 KiB of LDS per wave)
+
+struct FlatHit {  // 48 bytes: three 16-byte LDS reads per chunk
+    int64_t cfirst;   // first chunk of the hit's interior window (pool index / 8)
+    double sb;        // +-baseline
+    int g0lo;         // first window sample inside that chunk (0..7)
+    int wlen;         // interior window length
+    int ilo;          // record index of the first interior window sample
+    uint32_t sign;    // sign bit applied to y (positive polarity: first minimum of -y)
+    int P;            // chunks of the wave in front of this hit
+    int pad[3];
+};
+struct FlatLds {  // per wave
+    FlatHit hit[kFlatHits];
+    uint32_t flag[kFlatHits];  // 1: a numerator below the integer guard -> literal kernel
+    unsigned long long key[kFlatCap];
+    double sum[kFlatCap];
+    uint8_t map[kFlatCap];     // chunk of the batch -> hit
+};
+
+template <int W>
+__global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView rec, SgParams sg, RowParams rp,
+                                                          int4* __restrict__ desc, int64_t n_hits,
+                                                          uint8_t* __restrict__ out) {
+    constexpr int H = W / 2;
+    __shared__ __attribute__((aligned(16))) FlatLds s_lds;  // one wave per workgroup: its LDS and registers are free the moment it ends
+    FlatLds* __restrict__ lds = &s_lds;
+    const int lane = lane_id();
+    const int hq = lane;  // hit of the wave
+    const int64_t h_base = (int64_t)blockIdx.x * kFlatHits;
+    if (rp.n_dev && *rp.n_dev < n_hits) n_hits = *rp.n_dev;
+    if (h_base >= n_hits) return;  // whole wave beyond the rows of this pass
+
+    const int c0 = sg.itab[0];
+    uint32_t cq[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) cq[m] = ((uint32_t)sg.itab[2 * m + 1] & 0xffffu) | ((uint32_t)sg.itab[2 * m + 2] << 16);
+    const int bias_i = 32768 * sg.den;
+    const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
+
+    // ---- A: lane = hit ----
+    const int64_t h = h_base + hq;
+    int4 d = make_int4(0, 0, 0, 1);
+    if (h < n_hits) d = desc[h];
+    const bool work = h < n_hits && d.w == 0;
+    const int64_t r = d.x;
+    const int start = d.y, end = d.z;
+    int L = 0;
+    int64_t off = 0;
+    double baseline = 0.0;
+    bool positive = false;
+    if (work) {
+        baseline = rec.baseline[r];
+        if (rp.uni_L > 0) {
+            L = rp.uni_L;
+            off = rp.uni_off0 + r * (int64_t)(rp.uni_S ? rp.uni_S : rp.uni_L);
+            positive = rp.uni_positive != 0;
+        } else {
+            L = rec.len[r];
+            off = rec.off[r];
+            positive = rec.pol[r] == WFA_POL_POSITIVE;
+        }
+    }
+    const int seg_start = start - rp.le > 0 ? start - rp.le : 0;
+    const int seg_end = end + rp.re < rp.max_len ? end + rp.re : rp.max_len;
+    // interior part of the window (integer numerators); the <= 2H edge samples and the zero padding beyond the record
+    // (reference's dense matrix) are evaluated literally in C
+    const int ilo = seg_start > H ? seg_start : H;
+    const int ihi = seg_end < L - H ? seg_end : L - H;
+    // sig = +-(b - f64(y32)) is strictly monotone in y32 while the float64 subtraction is exact (|b| < 2^18, |y| < 2^17):
+    // the first maximum of sig is then the first extremum of y32 in float32 order; other baselines -> literal kernel
+    const bool y_order = fabs(baseline) < 262144.0;
+    bool need_literal = work && !y_order;
+    const bool has_int = work && y_order && ihi > ilo;
+    const int64_t g0 = off + ilo, g1 = off + ihi;
+    const int64_t c_first = g0 >> 3, c_last = has_int ? ((g1 - 1) >> 3) : -1;
+    const int n_chunks = has_int ? (int)(c_last - c_first + 1) : 0;
+    const double sb = positive ? -baseline : baseline;
+    int C;
+    const int my_P = wave_excl_scan_i32(n_chunks, C);
+    {
+        FlatHit fh;
+        fh.cfirst = c_first; fh.sb = sb; fh.g0lo = (int)(g0 - (c_first << 3)); fh.wlen = ihi - ilo; fh.ilo = ilo;
+        fh.sign = positive ? 0x80000000u : 0u; fh.P = my_P; fh.pad[0] = fh.pad[1] = fh.pad[2] = 0;
+        lds->hit[hq] = fh;
+        lds->flag[hq] = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint4* __restrict__ p16 = reinterpret_cast<const uint4*>(pool.u16);
+    unsigned long long acc_key = ~0ull;
+    double acc_sum = 0.0;
+
+    for (int f0 = 0; f0 < C; f0 += kFlatCap) {
+        const int f1 = f0 + kFlatCap < C ? f0 + kFlatCap : C;
+        const int lo = my_P > f0 ? my_P : f0;
+        const int hi = my_P + n_chunks < f1 ? my_P + n_chunks : f1;
+        for (int f = lo; f < hi; ++f) lds->map[f - f0] = (uint8_t)hq;  // chunk -> hit of this batch
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- B: lane = chunk; the loads of the next round of 64 chunks are in flight while this one is evaluated ----
+        // (unconditional loads at a clamped chunk number: a load behind a branch drags an `s_waitcnt vmcnt(0)` with it)
+        struct Fetched { FlatHit fh; uint4 vp, v, vn; int j; };
+        auto fetch = [&](int f) {
+            Fetched x;
+            const int fc = f < f1 ? f : f1 - 1;
+            x.fh = lds->hit[lds->map[fc - f0]];
+            x.j = fc - x.fh.P;
+            const int64_t c = x.fh.cfirst + x.j;
+            x.vp = p16[c > 0 ? c - 1 : 0]; x.v = p16[c]; x.vn = p16[c + 1];  // neighbours: same record (interior window)
+            return x;
+        };
+        Fetched nxt = fetch(f0 + lane);
+        for (int f = f0 + lane; __ballot(f < f1) != 0; f += kWave) {
+            const Fetched cur = nxt;
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = fetch(f + kWave);
+            __builtin_amdgcn_sched_barrier(0);
+            const FlatHit& fh = cur.fh;
+            const int j = cur.j;
+            const int hh = lds->map[(f < f1 ? f : f1 - 1) - f0];
+            const uint4 vp = cur.vp, v = cur.v, vn = cur.vn;
+            uint32_t E[12];
+            E[0] = vp.x ^ 0x80008000u; E[1] = vp.y ^ 0x80008000u; E[2] = vp.z ^ 0x80008000u; E[3] = vp.w ^ 0x80008000u;
+            E[4] = v.x ^ 0x80008000u; E[5] = v.y ^ 0x80008000u; E[6] = v.z ^ 0x80008000u; E[7] = v.w ^ 0x80008000u;
+            E[8] = vn.x ^ 0x80008000u; E[9] = vn.y ^ 0x80008000u; E[10] = vn.z ^ 0x80008000u; E[11] = vn.w ^ 0x80008000u;
+            int Z[8];  // numerators of the unbiased samples: n . x
+            sg_chunk_numerators_add<W>(E, c0, cq, bias_i, Z);
+            if (f < f1) {
+                // integer guard: the smallest numerator of the chunk (samples of it outside the window are ordinary
+                // neighbours of the same record: at worst a hit goes to the literal kernel that did not have to)
+                int zm = Z[0] < Z[1] ? Z[0] : Z[1];
+#pragma unroll
+                for (int k = 2; k < 8; ++k) zm = Z[k] < zm ? Z[k] : zm;
+                if (zm < guard) atomicOr(&lds->flag[hh], 1u);
+            }
+            const int rel0 = 8 * j - fh.g0lo;  // window-relative index of this chunk's sample 0
+            float ext_t = __builtin_huge_valf();
+            int ext_i = 0x7fffffff;
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in = (unsigned)(rel0 + k) < (unsigned)fh.wlen;
+                const float y32 = (float)((double)Z[k] * sg.rden);
+                // a sample outside the window gets t = +inf: it never wins the extremum and its signal is -inf, clamped to 0
+                const float t = in ? __uint_as_float(__float_as_uint(y32) ^ fh.sign) : __builtin_huge_valf();
+                const bool better = t < ext_t;  // ascending index: the first extremum is kept
+                ext_t = better ? t : ext_t;
+                ext_i = better ? fh.ilo + rel0 + k : ext_i;
+                sum += fmax(fh.sb - (double)t, 0.0);
+            }
+            if (f < f1) {
+                // float32 order as unsigned order: negative values with all bits flipped, the others with the sign bit set
+                const uint32_t u = __float_as_uint(ext_t);
+                const uint32_t ord = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+                lds->key[f - f0] = ((unsigned long long)ord << 32) | (uint32_t)ext_i;
+                lds->sum[f - f0] = sum;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- C (accumulation): lane = hit walks its chunks of the batch in order ----
+        for (int f = lo; f < hi; ++f) {
+            const unsigned long long k = lds->key[f - f0];
+            acc_key = k < acc_key ? k : acc_key;
+            acc_sum += lds->sum[f - f0];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // ---- C (rows): lane = hit ----
+    if (work) {
+        need_literal |= lds->flag[hq] != 0u;
+        HitAccAny acc{-__builtin_huge_val(), 0x7fffffff, acc_sum};
+        if (acc_key != ~0ull) {
+            const uint32_t ord = (uint32_t)(acc_key >> 32);
+            const uint32_t u = ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu);
+            acc.best = sb - (double)__uint_as_float(u);
+            acc.best_i = (int)(uint32_t)acc_key;
+        }
+        if (!need_literal && (seg_start < H || seg_end > L - H)) {
+            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, off, L);
+            HitCtx hc;
+            hc.L = L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
+            hc.thr = 0.0; hc.positive = positive; hc.baseline = baseline;
+            const int l_end = seg_end < H ? seg_end : H;              // left edge samples [seg_start, l_end)
+            for (int i = seg_start; i < l_end; ++i) acc.add(hit_signal<WFA_SRC_SG_FUSED>(src, hc, i), i);
+            const int r_beg = seg_start > L - H ? seg_start : L - H;  // right edge + padding [r_beg, seg_end)
+            for (int i = r_beg; i < seg_end; ++i) acc.add(hit_signal<WFA_SRC_SG_FUSED>(src, hc, i), i);
+        }
+        if (need_literal) desc[h].w = 2;  // below the integer guard: the literal kernel redoes this hit
+        else write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
+    }
+}
+
 // ---- exclusive scan of per-record hit counts (int32 -> int64 offsets) --------------------------
 constexpr int kScanTile = 1024;  // records per scan block (256 threads x 4)
 
@@ -3078,11 +3285,15 @@ hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bi
 }
 
 hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
-                                const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out) {
+                                const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out, bool grouped) {
     if (n_hits == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n_hits + kRowsHits - 1) / kRowsHits);
-#define WFA_ROWS(WW) \
-    case WW: hipLaunchKernelGGL((k_hit_rows_grp<WW>), dim3(grid), dim3(kRowsBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); break;
+    const unsigned grid_flat = (unsigned)((n_hits + kFlatHits - 1) / kFlatHits);
+#define WFA_ROWS(WW)                                                                                                              \
+    case WW:                                                                                                                      \
+        if (grouped) hipLaunchKernelGGL((k_hit_rows_grp<WW>), dim3(grid), dim3(kRowsBlock), 0, st, pool, rec, sg, rp, desc, n_hits, out); \
+        else hipLaunchKernelGGL((k_hit_rows_flat<WW>), dim3(grid_flat), dim3(kWave), 0, st, pool, rec, sg, rp, desc, n_hits, out);       \
+        break;
     switch (sg.W) {
         WFA_ROWS(5)
         WFA_ROWS(7)

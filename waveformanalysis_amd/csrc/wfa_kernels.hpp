@@ -222,8 +222,9 @@ hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_s
                                const int64_t* span_row0, int64_t cap, int4* desc);
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
                            const int64_t* out_start, int4* desc, const RowParams& rp);
+// grouped: the 8-lanes-per-hit kernel of rounds 1-2 (wfa_set_option "rows_grouped"); default: the flat chunk-per-lane kernel
 hipError_t launch_hit_rows_fast(hipStream_t st, const PoolView& pool, const RecView& rec, const SgParams& sg,
-                                const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out);
+                                const RowParams& rp, int4* desc, int64_t n_hits, uint8_t* out, bool grouped = false);
 hipError_t launch_hit_rows_literal(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                    const SgParams& sg, const RowParams& rp, const int4* desc, int64_t n_hits,
                                    bool only_flagged, uint8_t* out);

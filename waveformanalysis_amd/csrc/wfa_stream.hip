@@ -90,19 +90,6 @@ __device__ __forceinline__ void tile_wait_all(Tile32& d) {
 __device__ __forceinline__ uint32_t udot2_acc(uint32_t pair, uint32_t acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(wfa_u2, pair), __builtin_bit_cast(wfa_u2, 0x00010001u), acc, false);
 }
-__device__ __forceinline__ int wave_excl_scan_i32(int v, int& total) {
-    // inclusive scan over the 64 lanes with DPP row shifts / broadcasts, returned as exclusive
-    int s = v;
-    s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, true);  // row_shr:1
-    s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, true);  // row_shr:2
-    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, true);  // row_shr:4
-    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, true);  // row_shr:8
-    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
-    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
-    total = __builtin_amdgcn_readlane(s, 63);
-    return s - v;
-}
-
 }  // namespace
 
 // W: SG window (5..11).  BLW: 0 = records.baseline is given; 40 = baseline := mean of the first 40 samples, written
