@@ -1355,19 +1355,21 @@ __global__ __launch_bounds__(kRowsBlock) void k_hit_rows_grp(PoolView pool, RecV
 // lane.  The grouped kernel above gives every hit 8 lanes and iterates as long as the longest hit of a wave: half of all
 // hits are fragments of a few samples that fill one or two of their 8 lanes, and it issued 4.4 x the instructions the
 // window samples need (profiles/r02_pmc_sq_counters.txt: 257.6e6 for 2.1e6 hits).  Here every wave works on its own 64
-// hits, one wave per workgroup, no block barriers (measured on the way: 64 hits per 256-thread block with phases separated
-// by __syncthreads spent 74 % of its wave cycles waiting, 0.60 ms; 16 hits per wave with 4 lanes per hit 0.46 ms, with the
-// next round's loads in flight 0.42 ms = the grouped kernel's time at 0.6 x its instructions, but 70 per hit of them
-// per-hit bookkeeping that 64 hits per wave divide by four):
-//   A  lane = hit: window, first chunk, chunk count; a prefix sum of the counts numbers the wave's chunks;
-//   B  lane = chunk: three 16-byte loads (own chunk + both neighbours), 8 exact numerators, float32-ordered first extremum
-//      and clamped float64 sum of its in-window samples -> one (key, sum) pair per chunk in LDS, key = (ordered float32,
-//      sample index): the 64-bit minimum is the reference's first maximum of the signal;
-//   C  lane = hit: walk its chunks' pairs in order (a fixed order: the row bytes do not depend on scheduling), add the
-//      <= 2H edge samples / zero padding literally, write the row.
-// A wave whose hits hold more than kFlatCap chunks runs B and C in batches.
-constexpr int kFlatHits = 64;   // per wave
-constexpr int kFlatCap = 512;   // chunks per batch and wave (8 KiB of pairs: 12 KiB of LDS per wave)
+// hits, one wave per workgroup, no block barriers:
+//   A  lane = hit: window, first chunk, chunk count; a prefix sum of the counts numbers the wave's chunks, a bit per chunk
+//      that starts a hit + a popcount turn a chunk number back into its hit;
+//   B  lane = chunk, the next round's loads in flight: three 16-byte loads (own chunk + both neighbours), 8 exact
+//      numerators, then per hit in LDS with INTEGER atomics (any order gives the same bits)
+//        min of (float32 y in unsigned order, sample index)   = the reference's first maximum of the signal,
+//        sum of y * 2^23 and count over the samples with signal > 0 (y = float32: an exact integer above the guard),
+//      so that  integral = count * (+-baseline) - sum(y);
+//   C  lane = hit: the <= 2H edge samples / zero padding of the hits that have any go through a second, short chunk-style
+//      list (one sample per lane, literal float64 code), then the row.
+// Measured on the way (2.12e6 hits): 64 hits per 256-thread block with phases between __syncthreads 0.60 ms (74 % of the
+// wave cycles waiting); 16 hits per wave 0.46; + next round's loads in flight 0.42; 64 hits per wave with per-chunk pairs
+// in LDS walked by lane = hit 0.39 (54 instructions per hit, 30 of them the serial walks and one-lane edge loops).
+constexpr int kFlatHits = 64;    // per wave
+constexpr int kFlatCap = 2048;   // chunks per batch and wave (a start bit each)
 
 struct FlatHit {  // 48 bytes: three 16-byte LDS reads per chunk
     int64_t cfirst;   // first chunk of the hit's interior window (pool index / 8)
@@ -1377,15 +1379,43 @@ struct FlatHit {  // 48 bytes: three 16-byte LDS reads per chunk
     int ilo;          // record index of the first interior window sample
     uint32_t sign;    // sign bit applied to y (positive polarity: first minimum of -y)
     int P;            // chunks of the wave in front of this hit
-    int pad[3];
+    float tb;         // largest float32 below sb: signal > 0  <=>  t <= tb
+    int L;            // record length (edge list)
+    int seg_start;    // window start (edge list)
 };
 struct FlatLds {  // per wave
     FlatHit hit[kFlatHits];
-    uint32_t flag[kFlatHits];  // 1: a numerator below the integer guard -> literal kernel
-    unsigned long long key[kFlatCap];
-    double sum[kFlatCap];
-    uint8_t map[kFlatCap];     // chunk of the batch -> hit
+    unsigned long long key[kFlatHits];   // min over the hit's samples of (ordered float32 t, sample index)
+    unsigned long long tsum[kFlatHits];  // sum of t * 2^23 over the samples with signal > 0 (two's complement)
+    uint32_t npos[kFlatHits];            // how many
+    uint32_t flag[kFlatHits];            // 1: a numerator below the integer guard -> literal kernel
+    uint32_t start_bits[kFlatCap / 32];  // chunk f of the batch starts (continues, for bit 0) a hit
+    uint32_t word_rank[kFlatCap / 32];   // start bits in front of that word
+    uint8_t by_rank[kFlatHits];          // k-th hit of the batch that has chunks
+    double esig[kWave];                  // edge list: signal of one sample per lane
 };
+
+// chunk (or edge sample) number f of the current batch -> hit
+__device__ __forceinline__ int flat_hit_of(const FlatLds* lds, int fb) {
+    const uint32_t w = lds->start_bits[fb >> 5];
+    const int rank = (int)lds->word_rank[fb >> 5] + __popc(w & (0xffffffffu >> (31 - (fb & 31)))) - 1;
+    return lds->by_rank[rank];
+}
+// start bits of a batch: every lane offers the stretch [lo, hi) of its hit inside the batch window [f0, f0 + cap)
+__device__ __forceinline__ void flat_index_batch(FlatLds* lds, int lane, int f0, int lo, int hi) {
+    constexpr int kWords = kFlatCap / 32;
+    static_assert(kWords == kWave, "one start word per lane");
+    lds->start_bits[lane] = 0u;
+    const bool has = hi > lo;
+    const unsigned long long m = __ballot(has);
+    if (has) lds->by_rank[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (has) atomicOr(&lds->start_bits[(lo - f0) >> 5], 1u << ((lo - f0) & 31));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int total;
+    lds->word_rank[lane] = (uint32_t)wave_excl_scan_i32(__popc(lds->start_bits[lane]), total);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 
 template <int W>
 __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView rec, SgParams sg, RowParams rp,
@@ -1395,7 +1425,6 @@ __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView 
     __shared__ __attribute__((aligned(16))) FlatLds s_lds;  // one wave per workgroup: its LDS and registers are free the moment it ends
     FlatLds* __restrict__ lds = &s_lds;
     const int lane = lane_id();
-    const int hq = lane;  // hit of the wave
     const int64_t h_base = (int64_t)blockIdx.x * kFlatHits;
     if (rp.n_dev && *rp.n_dev < n_hits) n_hits = *rp.n_dev;
     if (h_base >= n_hits) return;  // whole wave beyond the rows of this pass
@@ -1408,7 +1437,7 @@ __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView 
     const int guard = sg.guard > INT32_MAX ? INT32_MAX : (int)sg.guard;
 
     // ---- A: lane = hit ----
-    const int64_t h = h_base + hq;
+    const int64_t h = h_base + lane;
     int4 d = make_int4(0, 0, 0, 1);
     if (h < n_hits) d = desc[h];
     const bool work = h < n_hits && d.w == 0;
@@ -1448,30 +1477,34 @@ __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView 
     int C;
     const int my_P = wave_excl_scan_i32(n_chunks, C);
     {
+        // signal of a sample > 0  <=>  (double)t < sb  <=>  t <= tb, the largest float32 below sb
+        float tb = (float)sb;
+        if ((double)tb >= sb) {
+            const uint32_t u = __float_as_uint(tb);
+            tb = __uint_as_float(tb > 0.0f ? u - 1u : (tb < 0.0f ? u + 1u : 0x80000001u));
+        }
         FlatHit fh;
         fh.cfirst = c_first; fh.sb = sb; fh.g0lo = (int)(g0 - (c_first << 3)); fh.wlen = ihi - ilo; fh.ilo = ilo;
-        fh.sign = positive ? 0x80000000u : 0u; fh.P = my_P; fh.pad[0] = fh.pad[1] = fh.pad[2] = 0;
-        lds->hit[hq] = fh;
-        lds->flag[hq] = 0u;
+        fh.sign = positive ? 0x80000000u : 0u; fh.P = my_P; fh.tb = tb; fh.L = L; fh.seg_start = seg_start;
+        lds->hit[lane] = fh;
+        lds->key[lane] = ~0ull;
+        lds->tsum[lane] = 0ull;
+        lds->npos[lane] = 0u;
+        lds->flag[lane] = 0u;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint4* __restrict__ p16 = reinterpret_cast<const uint4*>(pool.u16);
-    unsigned long long acc_key = ~0ull;
-    double acc_sum = 0.0;
 
     for (int f0 = 0; f0 < C; f0 += kFlatCap) {
         const int f1 = f0 + kFlatCap < C ? f0 + kFlatCap : C;
-        const int lo = my_P > f0 ? my_P : f0;
-        const int hi = my_P + n_chunks < f1 ? my_P + n_chunks : f1;
-        for (int f = lo; f < hi; ++f) lds->map[f - f0] = (uint8_t)hq;  // chunk -> hit of this batch
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        flat_index_batch(lds, lane, f0, my_P > f0 ? my_P : f0, my_P + n_chunks < f1 ? my_P + n_chunks : f1);
         // ---- B: lane = chunk; the loads of the next round of 64 chunks are in flight while this one is evaluated ----
         // (unconditional loads at a clamped chunk number: a load behind a branch drags an `s_waitcnt vmcnt(0)` with it)
-        struct Fetched { FlatHit fh; uint4 vp, v, vn; int j; };
+        struct Fetched { FlatHit fh; uint4 vp, v, vn; int j, hh; };
         auto fetch = [&](int f) {
             Fetched x;
             const int fc = f < f1 ? f : f1 - 1;
-            x.fh = lds->hit[lds->map[fc - f0]];
+            x.hh = flat_hit_of(lds, fc - f0);
+            x.fh = lds->hit[x.hh];
             x.j = fc - x.fh.P;
             const int64_t c = x.fh.cfirst + x.j;
             x.vp = p16[c > 0 ? c - 1 : 0]; x.v = p16[c]; x.vn = p16[c + 1];  // neighbours: same record (interior window)
@@ -1484,8 +1517,6 @@ __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView 
             nxt = fetch(f + kWave);
             __builtin_amdgcn_sched_barrier(0);
             const FlatHit& fh = cur.fh;
-            const int j = cur.j;
-            const int hh = lds->map[(f < f1 ? f : f1 - 1) - f0];
             const uint4 vp = cur.vp, v = cur.v, vn = cur.vn;
             uint32_t E[12];
             E[0] = vp.x ^ 0x80008000u; E[1] = vp.y ^ 0x80008000u; E[2] = vp.z ^ 0x80008000u; E[3] = vp.w ^ 0x80008000u;
@@ -1493,66 +1524,99 @@ __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView 
             E[8] = vn.x ^ 0x80008000u; E[9] = vn.y ^ 0x80008000u; E[10] = vn.z ^ 0x80008000u; E[11] = vn.w ^ 0x80008000u;
             int Z[8];  // numerators of the unbiased samples: n . x
             sg_chunk_numerators_add<W>(E, c0, cq, bias_i, Z);
-            if (f < f1) {
-                // integer guard: the smallest numerator of the chunk (samples of it outside the window are ordinary
-                // neighbours of the same record: at worst a hit goes to the literal kernel that did not have to)
-                int zm = Z[0] < Z[1] ? Z[0] : Z[1];
+            // integer guard: the smallest numerator of the chunk (samples of it outside the window are ordinary neighbours of
+            // the same record: at worst a hit goes to the literal kernel that did not have to).  Above it |y| >= 1, so every
+            // float32 y is a multiple of 2^-23.
+            int zm = Z[0] < Z[1] ? Z[0] : Z[1];
 #pragma unroll
-                for (int k = 2; k < 8; ++k) zm = Z[k] < zm ? Z[k] : zm;
-                if (zm < guard) atomicOr(&lds->flag[hh], 1u);
-            }
-            const int rel0 = 8 * j - fh.g0lo;  // window-relative index of this chunk's sample 0
+            for (int k = 2; k < 8; ++k) zm = Z[k] < zm ? Z[k] : zm;
+            const int rel0 = 8 * cur.j - fh.g0lo;  // window-relative index of this chunk's sample 0
             float ext_t = __builtin_huge_valf();
-            int ext_i = 0x7fffffff;
-            double sum = 0.0;
+            int ext_k = 0;
+            double tsum = 0.0;
+            int npos = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const bool in = (unsigned)(rel0 + k) < (unsigned)fh.wlen;
                 const float y32 = (float)((double)Z[k] * sg.rden);
-                // a sample outside the window gets t = +inf: it never wins the extremum and its signal is -inf, clamped to 0
+                // a sample outside the window gets t = +inf: it never wins the extremum and its signal is not > 0
                 const float t = in ? __uint_as_float(__float_as_uint(y32) ^ fh.sign) : __builtin_huge_valf();
                 const bool better = t < ext_t;  // ascending index: the first extremum is kept
                 ext_t = better ? t : ext_t;
-                ext_i = better ? fh.ilo + rel0 + k : ext_i;
-                sum += fmax(fh.sb - (double)t, 0.0);
+                ext_k = better ? k : ext_k;
+                const bool pos = t <= fh.tb;
+                tsum += (double)(pos ? t : 0.0f);  // exact: 8 float32 values
+                npos += pos ? 1 : 0;
             }
             if (f < f1) {
+                if (zm < guard) atomicOr(&lds->flag[cur.hh], 1u);
                 // float32 order as unsigned order: negative values with all bits flipped, the others with the sign bit set
                 const uint32_t u = __float_as_uint(ext_t);
                 const uint32_t ord = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
-                lds->key[f - f0] = ((unsigned long long)ord << 32) | (uint32_t)ext_i;
-                lds->sum[f - f0] = sum;
+                atomicMin(&lds->key[cur.hh], ((unsigned long long)ord << 32) | (uint32_t)(fh.ilo + rel0 + ext_k));
+                // tsum * 2^23 as a 64-bit integer (|tsum| < 2^20: high part < 2^22, low part < 2^21)
+                const double x = tsum * 8388608.0;
+                const int hi = (int)(x * (1.0 / 2097152.0));
+                const int lo = (int)(x - (double)hi * 2097152.0);
+                atomicAdd(&lds->tsum[cur.hh], (unsigned long long)((long long)hi * 2097152ll + (long long)lo));
+                atomicAdd(&lds->npos[cur.hh], (uint32_t)npos);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // ---- C (accumulation): lane = hit walks its chunks of the batch in order ----
-        for (int f = lo; f < hi; ++f) {
-            const unsigned long long k = lds->key[f - f0];
-            acc_key = k < acc_key ? k : acc_key;
-            acc_sum += lds->sum[f - f0];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    // ---- C (rows): lane = hit ----
-    if (work) {
-        need_literal |= lds->flag[hq] != 0u;
-        HitAccAny acc{-__builtin_huge_val(), 0x7fffffff, acc_sum};
-        if (acc_key != ~0ull) {
-            const uint32_t ord = (uint32_t)(acc_key >> 32);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ---- C: lane = hit ----
+    need_literal |= work && lds->flag[lane] != 0u;
+    HitAccAny acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
+    {
+        const unsigned long long key = lds->key[lane];
+        if (work && key != ~0ull) {
+            const uint32_t ord = (uint32_t)(key >> 32);
             const uint32_t u = ord ^ ((ord >> 31) ? 0x80000000u : 0xffffffffu);
             acc.best = sb - (double)__uint_as_float(u);
-            acc.best_i = (int)(uint32_t)acc_key;
+            acc.best_i = (int)(uint32_t)key;
+            acc.sum = (double)lds->npos[lane] * sb - (double)(long long)lds->tsum[lane] * (1.0 / 8388608.0);
         }
-        if (!need_literal && (seg_start < H || seg_end > L - H)) {
-            WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, off, L);
-            HitCtx hc;
-            hc.L = L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
-            hc.thr = 0.0; hc.positive = positive; hc.baseline = baseline;
-            const int l_end = seg_end < H ? seg_end : H;              // left edge samples [seg_start, l_end)
-            for (int i = seg_start; i < l_end; ++i) acc.add(hit_signal<WFA_SRC_SG_FUSED>(src, hc, i), i);
-            const int r_beg = seg_start > L - H ? seg_start : L - H;  // right edge + padding [r_beg, seg_end)
-            for (int i = r_beg; i < seg_end; ++i) acc.add(hit_signal<WFA_SRC_SG_FUSED>(src, hc, i), i);
+    }
+    // edge list: the samples [seg_start, min(seg_end, H)) and [max(seg_start, L - H), seg_end) of every hit that has any,
+    // one per lane, evaluated with the reference's float64 code; their hits then take them in ascending order
+    {
+        const bool edgy = work && !need_literal;
+        const int l_end = seg_end < H ? seg_end : H;
+        const int nl = edgy && l_end > seg_start ? l_end - seg_start : 0;        // left edge samples
+        const int r_beg = seg_start > L - H ? seg_start : L - H;
+        const int nr = edgy && seg_end > r_beg ? seg_end - r_beg : 0;            // right edge samples + padding
+        int E_tot;
+        const int my_E = wave_excl_scan_i32(nl + nr, E_tot);
+        for (int e0 = 0; e0 < E_tot; e0 += kWave) {
+            const int e1 = e0 + kWave < E_tot ? e0 + kWave : E_tot;
+            const int lo = my_E > e0 ? my_E : e0, hi = my_E + nl + nr < e1 ? my_E + nl + nr : e1;
+            flat_index_batch(lds, lane, e0, lo, hi);
+            // the edge list's prefix of a hit is carried by the hit's lane; ds_bpermute brings it to the sample's lane (all
+            // lanes take part: an inactive source lane would deliver nothing)
+            const int hh = flat_hit_of(lds, e0 + lane < e1 ? lane : e1 - e0 - 1);
+            const int my_E_h = __shfl(my_E, hh, kWave), nl_h = __shfl(nl, hh, kWave), r_beg_h = __shfl(r_beg, hh, kWave);
+            if (e0 + lane < e1) {
+                const FlatHit fh = lds->hit[hh];
+                const int k = e0 + lane - my_E_h;
+                const int i = k < nl_h ? fh.seg_start + k : r_beg_h + (k - nl_h);
+                const int64_t off_h = (fh.cfirst << 3) + fh.g0lo - fh.ilo;
+                WaveSrc<WFA_SRC_SG_FUSED> src = make_src<WFA_SRC_SG_FUSED>(pool, sg, off_h, fh.L);
+                HitCtx hc;
+                hc.L = fh.L; hc.max_len = rp.max_len; hc.le = rp.le; hc.re = rp.re;
+                hc.thr = 0.0; hc.positive = fh.sign != 0u; hc.baseline = fh.sign ? -fh.sb : fh.sb;
+                lds->esig[lane] = hit_signal<WFA_SRC_SG_FUSED>(src, hc, i);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int e = lo; e < hi; ++e) {
+                const int k = e - my_E;
+                acc.add(lds->esig[e - e0], k < nl ? seg_start + k : r_beg + (k - nl));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+    }
+    if (work) {
         if (need_literal) desc[h].w = 2;  // below the integer guard: the literal kernel redoes this hit
         else write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
     }
