@@ -67,6 +67,11 @@ int wfa_last_error(char* buf, size_t buf_len);
 int wfa_ctx_create(int device_id, wfa_ctx** out);
 void wfa_ctx_destroy(wfa_ctx* ctx);
 int wfa_sync(wfa_ctx* ctx);
+/* Free the device scratch a later call rebuilds by itself (hit bitmap, run-event buffer, padded shadow pool, candidate
+ * and sort buffers, filter scratch); the resident pools, the records, the plan and the rows of the last passes stay.
+ * This is what Plugin.cleanup(context) of the HIP plugins calls (core/plugins/core/base.py:608-613: "releasing
+ * resources" after compute()).  freed_bytes (nullable) receives the capacity given back. */
+int wfa_release_scratch(wfa_ctx* ctx, int64_t* freed_bytes);
 /* Choice between code paths that produce identical results (no counterpart in the reference: its plugins have one
  * code path).  For tests, which compare the paths with each other, and for measurement; a caller never needs it.
  * Names: "no_fast" (literal float64 hit kernel), "no_span" (per-record mask kernel), "no_pad" (no padded shadow

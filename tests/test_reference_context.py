@@ -21,6 +21,14 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "waveform_an
 
 class OracleSession:
     calls = 0
+    n_samples = n_records = 0
+    timers = False
+
+    def profile(self, on=True):           # the session's HIP-event timers (a fixed answer here)
+        self.timers = on
+
+    def profile_report(self):
+        return {"k_oracle": (2.0, 1)} if self.timers else {}
 
     def upload_records(self, rec, thr=10.0, polarity=None):
         self.rec, self.thr = rec, thr
@@ -54,7 +62,8 @@ def ref_env(tmp_path, monkeypatch):
 
     def resident(context, pool, pool_filtered=None, **_kw):
         sess.pool = pool
-        return sess
+        sess.n_samples = pool.size
+        return K.note_session(sess)
 
     monkeypatch.setattr(K, "resident_session", resident)
     OracleSession.calls = 0
@@ -116,6 +125,13 @@ def test_hip_plugins_inside_reference_context(ref_env):
     assert len(df) == len(rec) and {"area", "height", "amp", "max_abs_diff"} <= set(df.columns)
     np.testing.assert_array_equal(df["height"].to_numpy(), np.asarray(features["height"]))
     assert OracleSession.calls == 2
+    # the Context's own Profiler (core/foundation/utils.py:92-207) holds the device section and its kernels next to the
+    # reference's `plugin.<name>.compute` key (context_execution.py:147)
+    prof = ctx.profiler
+    assert prof.counts["plugin.hit_threshold.compute"] == 1 and prof.counts["plugin.hit_threshold.hip"] == 1
+    assert prof.durations["plugin.hit_threshold.hip.k_oracle"] == pytest.approx(2.0e-3)
+    assert prof.counts["plugin.basic_features.hip.k_oracle"] == 1
+    assert ctx.get_plugin("hit_threshold").device_stats["gsamples_per_s"] == pytest.approx(len(pool) / 2.0e-3 / 1e9)
 
     # a second Context on the same storage loads from disk: no compute
     ctx2, _r, _p = _context(ref_env / "hip")
@@ -149,6 +165,9 @@ def test_hip_plugins_inside_reference_context(ref_env):
     assert OracleSession.calls == 2                                                # nothing was recomputed on the way
 
 
+from waveformanalysis_amd.device import DevicePool
+
+
 class OracleStreamSession:
     """Stand-in for a borrowed DeviceSession on the streaming path (upload, enqueue, wait): answers with the oracle."""
 
@@ -174,24 +193,30 @@ class OracleStreamSession:
         return self.rows
 
 
-class OraclePool:
+class OraclePool(DevicePool):
+    """The product's DevicePool over the oracle-backed stand-in session; counts what the streaming driver borrows."""
+
     def __init__(self):
+        super().__init__(device_ids=[0], session_factory=lambda dev: OracleStreamSession())
         self.borrowed = 0
         self.live = 0
         self.max_live = 0
 
-    def borrow(self):
+    def borrow_many(self, n):
         import contextlib
+
+        inner = super().borrow_many(n)
 
         @contextlib.contextmanager
         def cm():
-            self.borrowed += 1
-            self.live += 1
+            self.borrowed += n
+            self.live += n
             self.max_live = max(self.max_live, self.live)
             try:
-                yield OracleStreamSession()
+                with inner as got:
+                    yield got
             finally:
-                self.live -= 1
+                self.live -= n
 
         return cm()
 

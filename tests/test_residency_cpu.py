@@ -124,7 +124,95 @@ def test_real_session_methods_reset_tags():
     for name in ("upload_pool", "pool_gather", "close"):
         assert "forget_resident" in inspect.getsource(getattr(D.DeviceSession, name)), name
     for name in ("upload_filtered_pool", "savgol", "sosfiltfilt"):
-        assert "_res_filtered = None" in inspect.getsource(getattr(D.DeviceSession, name)), name
+        assert "_drop_f32_tags" in inspect.getsource(getattr(D.DeviceSession, name)), name
+
+
+def test_float32_pool_tag_is_dropped_when_a_filter_overwrites_the_device_buffer():
+    """a float32 array uploaded as the pool and a filter output share one device buffer.  After savgol /
+    sosfiltfilt / upload_filtered_pool the array remembered as the resident pool is no longer what the device holds."""
+    s = FakeSession()
+    f32 = np.arange(64, dtype=np.float32)
+    assert s.ensure_pool(f32) and not s.ensure_pool(f32)
+    s._drop_f32_tags()                       # what savgol(), sosfiltfilt(), upload_filtered_pool() do first
+    assert s._res_pool is None and s.ensure_pool(f32)
+    u16 = np.arange(64, dtype=np.uint16)     # a uint16 pool lives in the other device buffer: its tag stays
+    assert s.ensure_pool(u16)
+    s._drop_f32_tags()
+    assert not s.ensure_pool(u16)
+
+
+def test_borrow_many_is_atomic_and_spreads_over_devices():
+    """ADVICE r2 (low / medium): two sessions are taken under one lock (nested borrow() calls of concurrent pipelines
+    could each hold one and wait for ever), and a ring of sessions covers every device of the pool."""
+    import threading
+
+    class S:
+        def __init__(self, dev):
+            self.device_id = dev
+
+        def close(self):
+            pass
+
+    pool = D.DevicePool(device_ids=[0, 1, 2, 3], session_factory=S)
+    with pool.borrow_many(8) as ring:
+        assert [s.device_id for s in ring] == [0, 1, 2, 3, 0, 1, 2, 3]
+    with pool.borrow_many(4) as ring:       # reuse of free sessions: still one per device
+        assert sorted(s.device_id for s in ring) == [0, 1, 2, 3]
+    with pytest.raises(ValueError, match="cannot borrow"):
+        with pool.borrow_many(pool.max_sessions + 1):
+            pass
+    small = D.DevicePool(device_ids=[0], max_sessions=2, session_factory=S)
+    order = []
+
+    def pipeline(tag):
+        with small.borrow_many(2) as pair:
+            order.append((tag, "in", len(pair)))
+            threading.Event().wait(0.05)
+            order.append((tag, "out", len(pair)))
+
+    threads = [threading.Thread(target=pipeline, args=(k,)) for k in range(3)]
+    [t.start() for t in threads]
+    [t.join(timeout=10) for t in threads]
+    assert not any(t.is_alive() for t in threads), "deadlock"
+    assert [e[1] for e in order] == ["in", "out"] * 3      # one pipeline at a time holds both sessions
+    with pytest.raises(ValueError, match="cannot borrow"):
+        with D.DevicePool(device_ids=[0], max_sessions=1, session_factory=S).borrow_many(2):
+            pass
+
+
+def test_hit_stream_pipeline_uses_every_device_of_the_pool():
+    """the streaming hit pipeline drives two sessions per device: chunk k on device k mod n."""
+    from tests.bench_stub import Session
+    from waveformanalysis_amd import synth
+    from waveformanalysis_amd.plugin_api import SimpleContext
+    from waveformanalysis_amd.streaming import HipThresholdHitStream, records_to_chunks
+
+    staged = []
+
+    class Spy(Session):
+        def upload_pool(self, pool):
+            staged.append(self.device_id)
+            super().upload_pool(pool)
+
+        def _hits(self):  # no rows: the driver's chunk checks have nothing to object to
+            return 0
+
+    rec, pool = synth.make_run(1200, "v1725", cfg=3, threads=1)
+    ctx = SimpleContext({"wave_source": "records"}, {"records": rec, "wave_pool": pool})
+    dp = D.DevicePool(device_ids=[0, 1, 2, 3], session_factory=Spy)
+    plugin = HipThresholdHitStream(use_filtered=False, max_len=800, device_pool=dp)
+    chunks = records_to_chunks(rec, 100, "run")
+    timeline = []
+    outs = plugin.run_chunks(chunks, ctx, "run", max_workers=8, timeline=timeline)
+    assert len(outs) == len(chunks) == 12 and [t[0] for t in timeline] == list(range(12))
+    assert staged == [k % 4 for k in range(12)]
+    # chunk k + 1 .. k + 7 are queued before anybody waits for chunk k (ring of 8 sessions)
+    for (k, _b, queued, collected), later in zip(timeline, timeline[1:]):
+        assert queued <= later[1] <= later[2] <= collected
+    # the executor knob caps the ring: two workers = the double buffer on two devices
+    staged.clear()
+    plugin.run_chunks(chunks, ctx, "run", max_workers=2)
+    assert set(staged) == {0, 1}
 
 
 def test_device_pool_bounds_live_sessions_across_compute_calls():

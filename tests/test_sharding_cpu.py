@@ -10,6 +10,7 @@ import pytest
 
 from oracle import wfa_oracle as O
 from tests import golden_util as G
+from tests.dist_util import gather_rows_torch
 from waveformanalysis_amd import sharding, synth
 from waveformanalysis_amd.streaming import Chunk, records_to_chunks
 
@@ -29,7 +30,7 @@ def _worker(rank, world, port, n_records, out_path):
     rec, pool = synth.make_run(n_records, "v1725", cfg=5, threads=1)
     shard = sharding.make_shard(rec, pool, world, rank)
     hits = O.threshold_hits_chunked(shard.records, shard.wave_pool)  # stand-in for the HIP pass
-    gathered = sharding.gather_rows_torch(hits, root=0)
+    gathered = gather_rows_torch(hits, root=0)
     if rank == 0:
         shards = [sharding.make_shard(rec, pool, world, r) for r in range(world)]
         merged = sharding.merge_rows(gathered, [s.orig_index for s in shards], [s.records for s in shards])

@@ -35,6 +35,7 @@ SIGNATURES = {
     "wfa_ctx_create": (_int, [_int, C.POINTER(_p)]),
     "wfa_ctx_destroy": (None, [_p]),
     "wfa_sync": (_int, [_p]),
+    "wfa_release_scratch": (_int, [_p, C.POINTER(_i64)]),
     "wfa_set_option": (_int, [_p, C.c_char_p, _int]),
     "wfa_last_h2d_rate": (_int, [_p, C.POINTER(_f64)]),
     "wfa_hit_rows_source": (_int, [_p, _int]),

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "wfa_common.hpp"
+#include "wfa_host.hpp"
 #include "wfa_kernels.hpp"
 
 namespace wfa {
@@ -57,23 +58,9 @@ static int use_device(wfa_ctx* c) {
 
 constexpr size_t kStageBytes = 32u << 20;   // per staging buffer
 constexpr size_t kStageMin = 4u << 20;      // smaller copies go straight through hipMemcpyAsync
-constexpr int kStageThreads = 4;
 
-static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    if (bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
-    std::thread th[kStageThreads - 1];
-    const size_t part = (bytes / kStageThreads + 4095) & ~(size_t)4095;
-    for (int t = 1; t < kStageThreads; ++t) {
-        const size_t o = (size_t)t * part;
-        if (o >= bytes) break;
-        const size_t n = o + part < bytes ? part : bytes - o;
-        th[t - 1] = std::thread([=] { memcpy((char*)dst + o, (const char*)src + o, n); });
-    }
-    memcpy(dst, src, part < bytes ? part : bytes);
-    for (auto& x : th) if (x.joinable()) x.join();
-}
-
-// host -> device through the context's pinned double buffer (see wfa_ctx::stage); returns when the last chunk is queued
+// host -> device through the context's pinned double buffer (see wfa_ctx::stage; the ring itself: wfa_host.hpp); returns
+// when the last chunk has landed
 static int h2d_staged(wfa_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c->stage[0]) {
         for (int b = 0; b < 2; ++b) {
@@ -83,16 +70,16 @@ static int h2d_staged(wfa_ctx* c, void* dst, const void* src, size_t bytes) {
         c->stage_bytes = kStageBytes;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    bool used[2] = {false, false};
-    int b = 0;
-    for (size_t off = 0; off < bytes; off += kStageBytes, b ^= 1) {
-        const size_t n = bytes - off < kStageBytes ? bytes - off : kStageBytes;
-        if (used[b]) WFA_HIP_CHECK(hipEventSynchronize(c->stage_ev[b]));  // the copy out of this buffer has finished
-        parallel_memcpy(c->stage[b], (const char*)src + off, n);
-        WFA_HIP_CHECK(hipMemcpyAsync((char*)dst + off, c->stage[b], n, hipMemcpyHostToDevice, c->stream));
-        WFA_HIP_CHECK(hipEventRecord(c->stage_ev[b], c->stream));
-        used[b] = true;
-    }
+    hipError_t err = hipSuccess;
+    const int rc = host::staged_copy(
+        dst, src, bytes, c->stage, kStageBytes,
+        [&](void* d, const void* staged, size_t n, int b) {
+            err = hipMemcpyAsync(d, staged, n, hipMemcpyHostToDevice, c->stream);
+            if (err == hipSuccess) err = hipEventRecord(c->stage_ev[b], c->stream);
+            return err == hipSuccess ? 0 : 1;
+        },
+        [&](int b) { return (err = hipEventSynchronize(c->stage_ev[b])) == hipSuccess ? 0 : 1; });
+    if (rc) return fail(WFA_E_HIP, "staged upload failed: %s", hipGetErrorString(err));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));  // the staging buffers are free again for the next call
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (s > 0) c->last_h2d_GBps = (double)bytes / s / 1e9;
@@ -678,6 +665,29 @@ void wfa_ctx_destroy(wfa_ctx* c) {
     c->prof_free.clear();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int wfa_release_scratch(wfa_ctx* c, int64_t* freed_bytes) {
+    if (!c) return fail(WFA_E_INVALID, "null context");
+    WFA_HIP_CHECK(hipSetDevice(c->device));
+    if (c->stream) WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    // what a later call rebuilds by itself.  Kept: the resident pools, the records columns, the filter plan, the rows of the
+    // last passes (hit_out / hit_desc / peak_out / out_rows / gathered: *_fill and the resident hit-table stages read them),
+    // the decoded CSV samples (source of wfa_pool_gather), the pinned staging ring and the small control blocks.
+    DevBuf* bufs[] = {&c->bitmap, &c->hit_tmp, &c->bw_scratch, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val,
+                      &c->peak_slot_pos, &c->peak_slot_val, &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept,
+                      &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->fw_ties, &c->run_ev,
+                      &c->shadow_pool, &c->shadow_off};
+    int64_t freed = 0;
+    for (DevBuf* b : bufs) { freed += (int64_t)b->cap; b->release(); }
+    for (DevBuf& b : c->ht) { freed += (int64_t)b.cap; b.release(); }  // (a count pass without its fill is void after this)
+    c->ht_n = -1;
+    c->ht_perm = nullptr;
+    c->bitmap_clean = false;
+    c->shadow_valid = false;
+    c->hit_tmp_rows = 0;
+    if (freed_bytes) *freed_bytes = freed;
+    return WFA_OK;
 }
 
 int wfa_set_option(wfa_ctx* c, const char* name, int value) {

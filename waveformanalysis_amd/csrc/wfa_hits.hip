@@ -11,6 +11,7 @@
 #include <rocprim/functional.hpp>
 
 #include "wfa_common.hpp"
+#include "wfa_host.hpp"
 #include "wfa_numpy.hpp"
 
 namespace wfa {
@@ -950,36 +951,10 @@ int wfa_v1725_index(const uint8_t* buf, int64_t n_bytes, int64_t capacity, int16
     if (n_bytes < 0 || capacity < 0 || !n_waves || (n_bytes > 0 && !buf)) return fail(WFA_E_INVALID, "bad arguments");
     if (capacity > 0 && (!channel || !timestamp || !trunc || !baseline || !payload_offset || !n_samples))
         return fail(WFA_E_INVALID, "null output column");
-    int64_t pos = 0, k = 0;
-    bool stop = false;
-    while (!stop && n_bytes - pos >= 16) {  // a short event header ends the stream
-        const uint8_t* eh = buf + pos;
-        pos += 16;
-        const unsigned mask = (unsigned)eh[4] | ((unsigned)eh[11] << 8);
-        for (int ch = 0; ch < 16 && !stop; ++ch) {
-            if (!((mask >> ch) & 1u)) continue;
-            if (n_bytes - pos < 12) { pos = n_bytes; stop = true; break; }  // short channel header
-            const uint8_t* h = buf + pos;
-            pos += 12;
-            const int64_t ch_size = ((int64_t)h[0] | ((int64_t)h[1] << 8) | ((int64_t)h[2] << 16)) & 0x3fffff;
-            if (ch_size < 3) return fail(WFA_E_INVALID, "V1725 channel size %lld < 3 words at byte %lld", (long long)ch_size, (long long)(pos - 12));
-            const int64_t sig_bytes = (ch_size - 3) << 2;
-            if (n_bytes - pos < sig_bytes) { pos = n_bytes; stop = true; break; }  // short waveform
-            if (k < capacity) {
-                int64_t ts = 0;
-                for (int b = 5; b >= 0; --b) ts = (ts << 8) | h[4 + b];
-                channel[k] = (int16_t)ch;
-                timestamp[k] = ts;
-                trunc[k] = (uint8_t)((h[3] >> 6) & 1u);
-                baseline[k] = (uint16_t)(h[10] | (h[11] << 8));
-                payload_offset[k] = pos;
-                n_samples[k] = (int32_t)(sig_bytes >> 1);
-            }
-            ++k;
-            pos += sig_bytes;
-        }
-    }
-    *n_waves = k;
+    char err[160];
+    if (host::v1725_index(buf, n_bytes, capacity, channel, timestamp, trunc, baseline, payload_offset, n_samples, n_waves, err,
+                          sizeof(err)))
+        return fail(WFA_E_INVALID, "%s", err);
     return WFA_OK;
 }
 

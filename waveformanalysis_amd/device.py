@@ -90,6 +90,13 @@ class DeviceSession:
         self._res_pool = None
         self._res_filtered = None
 
+    def _drop_f32_tags(self) -> None:
+        """The device float32 buffer is about to be overwritten: forget every host array remembered as its content (the
+        filtered twin, and a float32 array that was uploaded as the pool itself)."""
+        self._res_filtered = None
+        if self._res_pool is not None and self._res_pool.dtype == np.float32:
+            self._res_pool = None
+
     def ensure_pool(self, wave_pool: np.ndarray, cacheable: bool = True) -> bool:
         """Upload `wave_pool` unless this very array object is what the device pool already holds.
 
@@ -144,7 +151,7 @@ class DeviceSession:
         arr = np.ascontiguousarray(pool_f32, dtype=np.float32)
         if self.n_samples and arr.size != self.n_samples:
             raise ValueError(f"wave_pool_filtered has {arr.size} samples, wave_pool has {self.n_samples}")
-        self._res_filtered = None
+        self._drop_f32_tags()
         _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
         self.uploads += 1
 
@@ -207,7 +214,7 @@ class DeviceSession:
 
     def savgol(self, download: bool = True) -> np.ndarray | None:
         out = np.empty(self.n_samples, dtype=np.float32) if download else None
-        self._res_filtered = None  # the device float32 pool is this filter's output now
+        self._drop_f32_tags()  # the device float32 pool is this filter's output now
         _lib.check(self._lib.wfa_savgol(self._h, _ptr(out)))
         return out
 
@@ -219,7 +226,7 @@ class DeviceSession:
         if sos.ndim != 2 or sos.shape[1] != 6 or zi.shape != (sos.shape[0], 2):
             raise ValueError("sos must be (n_sections, 6) and zi (n_sections, 2)")
         out = np.empty(self.n_samples, dtype=np.float32) if download else None
-        self._res_filtered = None
+        self._drop_f32_tags()
         _lib.check(self._lib.wfa_sosfiltfilt(self._h, int(sos.shape[0]), _ptr(sos), _ptr(zi), int(padlen), _ptr(out)))
         return out
 
@@ -477,6 +484,13 @@ class DeviceSession:
     def sync(self) -> None:
         _lib.check(self._lib.wfa_sync(self._h))
 
+    def release_scratch(self) -> int:
+        """Give back the device scratch later calls rebuild by themselves (wfa_release_scratch); returns the bytes freed.
+        The resident pools, records, plan and the rows of the last passes stay."""
+        freed = C.c_int64(0)
+        _lib.check(self._lib.wfa_release_scratch(self._h, C.byref(freed)))
+        return int(freed.value)
+
     def last_h2d_rate(self) -> float:
         """GB/s of the last large upload through the pinned staging ring."""
         v = C.c_double(0.0)
@@ -581,22 +595,59 @@ class DevicePool:
             self._local.session = s
         return s
 
+    def peek_session(self) -> DeviceSession | None:
+        """The session bound to the calling thread, if it has one (never creates one)."""
+        return getattr(self._local, "session", None)
+
+    def drop_session(self) -> bool:
+        """Close the calling thread's session (a plugin failed on it: its device state is not trusted any more); the
+        next session() call of this thread starts from a new context."""
+        s = getattr(self._local, "session", None)
+        if s is None:
+            return False
+        with self._lock:
+            self._thread_bound.discard(s)
+        self._local.session = None
+        s.close()
+        return True
+
     @contextlib.contextmanager
     def borrow(self):
+        with self.borrow_many(1) as got:
+            yield got[0]
+
+    @contextlib.contextmanager
+    def borrow_many(self, n: int):
+        """`n` sessions at once, taken atomically (two callers that each hold one session and wait for a second would
+        wait for ever), on as many different devices as the pool has: free sessions are preferred by device, new ones
+        are created round-robin.  Raises when the pool can never hold that many."""
+        n = int(n)
+        if n < 1 or n > self.max_sessions:
+            raise ValueError(f"cannot borrow {n} sessions from a pool of max_sessions={self.max_sessions}")
         with self._lock:
-            while not self._free and self._borrowable >= self.max_sessions:
+            while len(self._free) + (self.max_sessions - self._borrowable) < n:
                 self._lock.wait()
-            if self._free:
-                s = self._free.pop()
-            else:
-                s = self._new_session()
-                self._borrowable += 1
+            got: list[DeviceSession] = []
+            for _ in range(n):
+                used = [getattr(s, "device_id", None) for s in got]
+                # a free session on the device this borrower uses least, else a new one (round-robin over the devices)
+                pick = min(self._free, key=lambda s: used.count(getattr(s, "device_id", None)), default=None)
+                if pick is not None and (used.count(getattr(pick, "device_id", None)) == 0
+                                         or self._borrowable >= self.max_sessions):
+                    self._free.remove(pick)
+                    got.append(pick)
+                elif self._borrowable < self.max_sessions:
+                    got.append(self._new_session())
+                    self._borrowable += 1
+                else:
+                    self._free.remove(pick)
+                    got.append(pick)
         try:
-            yield s
+            yield got
         finally:
             with self._lock:
-                self._free.append(s)
-                self._lock.notify()
+                self._free.extend(got)
+                self._lock.notify_all()
 
     @property
     def live_sessions(self) -> int:

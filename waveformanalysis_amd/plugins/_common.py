@@ -8,6 +8,7 @@ Mirrors (does not import) the reference helpers:
 
 from __future__ import annotations
 
+import threading
 import warnings
 from typing import Any
 
@@ -16,10 +17,21 @@ import numpy as np
 from .. import _lib
 from ..channel_config import per_record_option, scatter_per_record
 from ..device import DeviceSession, default_pool
+from ..plugin_api import Plugin
 
 WAVE_SOURCE_AUTO = "auto"
 WAVE_SOURCE_RECORDS = "records"
 WAVE_SOURCES = {"auto", "records", "st_waveforms", "filtered_waveforms"}
+
+
+def _cfg(context: Any, plugin: Any, name: str):
+    """context.get_config(plugin, name); the option's default when `context` is not a Context (the reference's error
+    manager calls resolve_depends_on with its own context DICT, core/foundation/error.py:95)."""
+    get = getattr(context, "get_config", None)
+    if get is None:
+        opt = getattr(plugin, "options", {}).get(name)
+        return getattr(opt, "default", None)
+    return get(plugin, name)
 
 
 def normalize_wave_source(value: Any) -> str:
@@ -37,14 +49,14 @@ def records_dependencies(context: Any, plugin: Any) -> tuple[list[str], str]:
     The HIP plugins are records-backed: wave_source must be "records" (their default) --
     the dense st_waveforms / filtered_waveforms sources stay with the CPU plugins.
     """
-    source = normalize_wave_source(context.get_config(plugin, "wave_source"))
+    source = normalize_wave_source(_cfg(context, plugin, "wave_source"))
     if source != WAVE_SOURCE_RECORDS:
         raise ValueError(
             f"{plugin.provides} (HIP backend) reads records + wave_pool; set wave_source='records' "
             f"(got {source!r})."
         )
-    use_filtered = bool(context.get_config(plugin, "use_filtered")) if "use_filtered" in plugin.options else False
-    fused = bool(context.get_config(plugin, "fuse_filter")) if "fuse_filter" in plugin.options else False
+    use_filtered = bool(_cfg(context, plugin, "use_filtered")) if "use_filtered" in plugin.options else False
+    fused = bool(_cfg(context, plugin, "fuse_filter")) if "fuse_filter" in plugin.options else False
     if use_filtered and not fused:
         return ["records", "wave_pool_filtered"], "wave_pool_filtered"
     return ["records", "wave_pool"], "wave_pool"
@@ -59,8 +71,8 @@ def resolve_wave_input(context: Any, plugin: Any) -> tuple[str, list[str], str]:
     (cpu/_wave_source.py:74-172): kind is "records" or "dense"; data_name is the pool name for records,
     the structured-array name for dense.  An explicit wave_source wins; "auto" picks the dense array by
     use_filtered."""
-    source = normalize_wave_source(context.get_config(plugin, "wave_source"))
-    use_filtered = bool(context.get_config(plugin, "use_filtered")) if "use_filtered" in plugin.options else False
+    source = normalize_wave_source(_cfg(context, plugin, "wave_source"))
+    use_filtered = bool(_cfg(context, plugin, "use_filtered")) if "use_filtered" in plugin.options else False
     if source == WAVE_SOURCE_RECORDS:
         pool = "wave_pool_filtered" if use_filtered else "wave_pool"
         return "records", [WAVE_SOURCE_RECORDS, pool], pool
@@ -177,7 +189,7 @@ def resident_session(context: Any, pool: np.ndarray, pool_filtered: np.ndarray |
     pool_gather, the filters, close).  Pass cacheable=False for temporaries: dense `wave` fields, astype / asarray
     copies.  Arrays handed out by a Context (`get_data` memoises its results) are the cacheable case."""
     pool_obj = getattr(context, "wfa_device_pool", None) or default_pool()
-    sess = pool_obj.session()
+    sess = note_session(pool_obj.session())
     sess.ensure_pool(pool, cacheable=cacheable)
     if pool_filtered is not None:
         sess.ensure_filtered_pool(pool_filtered, cacheable=cacheable)
@@ -196,3 +208,139 @@ def invalidate_residency(context: Any = None) -> None:
 
 
 SRC_RAW, SRC_F32, SRC_SG_FUSED = _lib.SRC_RAW, _lib.SRC_F32, _lib.SRC_SG_FUSED
+
+
+# ---- the reference's profiling / statistics / cleanup hooks --------------------------------------
+def _device_pool(context: Any):
+    return getattr(context, "wfa_device_pool", None) or default_pool()
+
+
+def _hooks(context: Any):
+    """(profiler, stats collector) of a reference Context when they are switched on
+    (core/context_execution.py:140-149, core/foundation/utils.py:92-207, core/plugins/core/stats.py:103-520)."""
+    prof = getattr(context, "profiler", None)
+    if prof is not None and not hasattr(prof, "timeit"):
+        prof = None
+    stats = getattr(context, "stats_collector", None)
+    if stats is not None and not (hasattr(stats, "is_enabled") and stats.is_enabled()):
+        stats = None
+    return prof, stats
+
+
+def publish_device_report(context: Any, plugin: Any, report: dict, n_samples: int, n_records: int, n_rows: int) -> dict:
+    """Kernel times of one compute() into the Context's Profiler under `plugin.<name>.hip.<kernel>` (seconds, launches),
+    and the rates the reference has no counter for -- Gsamples/s and algorithmic HBM GB/s of the device section --
+    into `plugin.device_stats` and the stats collector (`hip_metrics[<name>]`, logged like its own records)."""
+    prof, stats = _hooks(context)
+    name = plugin.provides
+    device_s = sum(ms for ms, _n in report.values()) / 1e3
+    if prof is not None and hasattr(prof, "durations") and hasattr(prof, "counts"):
+        for kernel, (ms, launches) in report.items():
+            key = f"plugin.{name}.hip.{kernel}"
+            prof.durations[key] += ms / 1e3
+            prof.counts[key] += int(launches)
+    bps, bpr, bprow = getattr(plugin, "algorithmic_bytes", (2, 29, 0))
+    hbm_bytes = bps * n_samples + bpr * n_records + bprow * n_rows
+    stats_row = {
+        "samples": int(n_samples), "records": int(n_records), "rows": int(n_rows), "device_s": device_s,
+        "gsamples_per_s": (n_samples / device_s / 1e9) if device_s > 0 else 0.0,
+        "hbm_GBps_algorithmic": (hbm_bytes / device_s / 1e9) if device_s > 0 else 0.0,
+        "kernels_ms": {k: ms for k, (ms, _n) in report.items()},
+    }
+    plugin.device_stats = stats_row
+    if stats is not None:
+        table = getattr(stats, "hip_metrics", None)
+        if table is None:
+            table = stats.hip_metrics = {}
+        table.setdefault(name, []).append(stats_row)
+        import logging
+
+        logging.getLogger("waveform_analysis.core.plugins.core.stats").info(
+            "Plugin '%s' device section: %.3f ms, %.1f Gsamples/s, %.0f GB/s (algorithmic HBM bytes)",
+            name, device_s * 1e3, stats_row["gsamples_per_s"], stats_row["hbm_GBps_algorithmic"])
+    return stats_row
+
+
+_tls = threading.local()
+
+
+def note_session(sess):
+    """Called where a plugin takes its device session: while an instrumented compute() runs on this thread, the first
+    session it touches gets its kernel timers switched on (HIP events around every launch, resolved when read)."""
+    frame = getattr(_tls, "frame", None)
+    if frame is not None and frame["sess"] is None and hasattr(sess, "profile") and hasattr(sess, "profile_report"):
+        sess.profile(True)
+        frame["sess"] = sess
+    return sess
+
+
+def _instrument(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def compute(self, context, run_id, **kwargs):
+        self._wfa_failed = False
+        prof, stats = _hooks(context)
+        if prof is None and stats is None:
+            return fn(self, context, run_id, **kwargs)
+        outer = getattr(_tls, "frame", None)  # a plugin that pulls a dependency through the Context nests compute() calls
+        frame = _tls.frame = {"sess": None}
+        try:
+            if prof is not None:
+                with prof.timeit(f"plugin.{self.provides}.hip"):
+                    result = fn(self, context, run_id, **kwargs)
+            else:
+                result = fn(self, context, run_id, **kwargs)
+        finally:
+            _tls.frame = outer
+            sess, report = frame["sess"], None
+            if sess is not None:
+                try:
+                    report = sess.profile_report()
+                    sess.profile(False)
+                except Exception:  # the failure that brought us here is the one to report
+                    report = None
+        if report:
+            n_rows = len(result) if hasattr(result, "__len__") else 0
+            publish_device_report(context, self, report, getattr(sess, "n_samples", 0), getattr(sess, "n_records", 0), n_rows)
+        return result
+
+    compute._wfa_instrumented = True
+    return compute
+
+
+class HipPlugin(Plugin):
+    """Base of the plugins that run on the device: the Context's hooks around compute().
+
+    * profiler / stats (core/context_execution.py:146-149): when the Context has a Profiler or an enabled
+      PluginStatsCollector, the kernels of this compute() are timed with HIP events and published
+      (`publish_device_report`);
+    * cleanup(context) (core/plugins/core/base.py:608-613, always called after compute()): the device scratch the
+      next call rebuilds by itself is freed (`wfa_release_scratch`), the resident pool / records / rows stay; after a
+      failed compute() (`on_error`, base.py:602-606) the thread's session is closed: its device state is not trusted.
+    algorithmic_bytes = (per sample, per record, per output row) of the plugin's device pass."""
+
+    algorithmic_bytes = (2, 29, 0)
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        fn = cls.__dict__.get("compute")
+        if fn is not None and not getattr(fn, "_wfa_instrumented", False):
+            cls.compute = _instrument(fn)
+
+    def on_error(self, context: Any, exception: Exception) -> None:
+        self._wfa_failed = True
+
+    def cleanup(self, context: Any) -> None:
+        from .. import device as _device
+
+        pool_obj = getattr(context, "wfa_device_pool", None) or _device._default_pool  # never creates a pool here
+        peek = getattr(pool_obj, "peek_session", None)
+        sess = peek() if peek is not None else None
+        if sess is None:
+            return
+        if getattr(self, "_wfa_failed", False):
+            self._wfa_failed = False
+            pool_obj.drop_session()
+            return
+        sess.release_scratch()

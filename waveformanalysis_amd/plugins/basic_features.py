@@ -15,10 +15,11 @@ from . import _common as K
 PEAK_RANGE = (40, 90)  # reference: core/foundation/constants.py:22 (FeatureDefaults.PEAK_RANGE)
 
 
-class HipBasicFeaturesPlugin(Plugin):
+class HipBasicFeaturesPlugin(K.HipPlugin):
     """height / amp / area / max_abs_diff per record, computed on the GPU."""
 
     provides = "basic_features"
+    algorithmic_bytes = (2, 29 + 36, 0)  # device pass: bytes per sample, per record, per output row (SURVEY 8d)
     depends_on = []
     description = "Compute basic height, amplitude, area, and max-abs-diff features (HIP, gfx950)."
     version = "4.0.0+hip1"

@@ -19,8 +19,9 @@ from ..plugin_api import Option, Plugin
 from . import _common as K
 
 
-class HipFilteredWaveformsPlugin(Plugin):
+class HipFilteredWaveformsPlugin(K.HipPlugin):
     provides = "filtered_waveforms"
+    algorithmic_bytes = (2 + 4, 0, 0)  # device pass: bytes per sample, per record, per output row
     depends_on = ["st_waveforms"]
     description = "Apply filtering to waveforms using Butterworth or Savitzky-Golay filters (HIP, gfx950)."
     version = "3.0.0+hip1"

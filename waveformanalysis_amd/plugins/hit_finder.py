@@ -19,10 +19,11 @@ from ..plugin_api import Option, Plugin
 from . import _common as K
 
 
-class HipHitFinderPlugin(Plugin):
+class HipHitFinderPlugin(K.HipPlugin):
     """find_peaks-based hit detector with HIT_DTYPE output, computed on the GPU."""
 
     provides = "hit"
+    algorithmic_bytes = (4, 29, 48)  # device pass: bytes per sample, per record, per output row (SURVEY 8d)
     depends_on = []  # dynamic, see resolve_depends_on
     description = "Detect peaks in waveforms and extract peak features (HIP, gfx950)."
     version = "3.0.0+hip1"

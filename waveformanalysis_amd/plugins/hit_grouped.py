@@ -10,7 +10,7 @@ from ..plugin_api import Option, Plugin
 from . import _common as K
 
 
-class HipHitGroupedPlugin(Plugin):
+class HipHitGroupedPlugin(K.HipPlugin):
     """Group hits across channels into coincidence events (gap-chained absolute windows).
 
     Consumes `hit_merged` (+ `hit_merged_components` and `hit_threshold` for merged hits that span
@@ -20,6 +20,7 @@ class HipHitGroupedPlugin(Plugin):
     """
 
     provides = "hit_grouped"
+    algorithmic_bytes = (0, 0, 72)  # device pass: bytes per sample, per record, per output row
     depends_on = []  # dynamic, see resolve_depends_on
     description = "Group hits across channels into event-level coincidence windows (vectorised)."
     version = "0.5.0+hip1"
@@ -49,4 +50,4 @@ class HipHitGroupedPlugin(Plugin):
         pool_obj = getattr(context, "wfa_device_pool", None) or K.default_pool()
         return group_hit_windows(hits, time_window_ns=time_window_ns, dt_values=dt_values,
                                  component_rows=component_rows, component_hits=component_hits,
-                                 session=pool_obj.session())
+                                 session=K.note_session(pool_obj.session()))

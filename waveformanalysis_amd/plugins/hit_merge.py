@@ -21,7 +21,7 @@ MERGE_OPTIONS = {
 
 def _session(context):
     pool_obj = getattr(context, "wfa_device_pool", None) or K.default_pool()
-    return pool_obj.session()
+    return K.note_session(pool_obj.session())
 
 
 def _clusters_or_compute(context, run_id, hits, cfg_plugin):
@@ -37,10 +37,11 @@ def _clusters_or_compute(context, run_id, hits, cfg_plugin):
     return rows
 
 
-class HipHitMergeClustersPlugin(Plugin):
+class HipHitMergeClustersPlugin(K.HipPlugin):
     """Flat cluster membership of the per-channel hit merge."""
 
     provides = "hit_merge_clusters"
+    algorithmic_bytes = (0, 0, 60)  # hit rows in, index tables out
     depends_on = ["hit_threshold"]
     description = "Internal cluster membership rows shared by hit_merged outputs (HIP, gfx950)."
     version = "0.1.0+hip1"
@@ -58,10 +59,11 @@ class HipHitMergeClustersPlugin(Plugin):
         return M.compute_cluster_rows(_session(context), hits, gap, width, explicit_dt, self.provides)
 
 
-class HipHitMergePlugin(Plugin):
+class HipHitMergePlugin(K.HipPlugin):
     """Merge nearby hits from hit_threshold within the same channel."""
 
     provides = "hit_merged"
+    algorithmic_bytes = (0, 0, 60)  # hit rows in, index tables out
     depends_on = ["hit_threshold", "hit_merge_clusters"]
     description = "Merge nearby threshold hits per channel with time-gap and max-width constraints (HIP, gfx950)."
     version = "0.8.0+hip1"

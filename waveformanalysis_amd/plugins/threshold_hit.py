@@ -14,10 +14,11 @@ from ..sg_plan import normalize_window
 from . import _common as K
 
 
-class HipThresholdHitPlugin(Plugin):
+class HipThresholdHitPlugin(K.HipPlugin):
     """Threshold-only hit detector with THRESHOLD_HIT_DTYPE output, computed on the GPU."""
 
     provides = "hit_threshold"
+    algorithmic_bytes = (2, 29, 60)  # device pass: bytes per sample, per record, per output row (SURVEY 8d)
     depends_on = []  # dynamic, see resolve_depends_on
     description = "Threshold-only hit detector with THRESHOLD_HIT_DTYPE output (HIP, gfx950)."
     version = "0.11.0+hip1"

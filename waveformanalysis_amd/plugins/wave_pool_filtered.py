@@ -12,10 +12,11 @@ from ..filter_engine import design_bw, plan_filter_groups, run_filter_groups  # 
 from . import _common as K
 
 
-class HipWavePoolFilteredPlugin(Plugin):
+class HipWavePoolFilteredPlugin(K.HipPlugin):
     """Build the float32 filtered wave_pool on the GPU (Savitzky-Golay, interpolated edges)."""
 
     provides = "wave_pool_filtered"
+    algorithmic_bytes = (2 + 4, 0, 0)  # device pass: bytes per sample, per record, per output row (SURVEY 8d)
     depends_on = ["records", "wave_pool"]
     description = "Build filtered wave_pool from records-backed raw waveforms (HIP, gfx950)."
     version = "3.0.0+hip1"

@@ -30,10 +30,11 @@ def first_row_of_record_id(row_record_ids: np.ndarray, wanted: np.ndarray) -> np
     return np.where(found, first[pos_c] if len(ids) else -1, -1).astype(np.int64)
 
 
-class HipWaveformWidthPlugin(Plugin):
+class HipWaveformWidthPlugin(K.HipPlugin):
     """Rise / fall / total width per detected peak, computed on the GPU."""
 
     provides = "waveform_width"
+    algorithmic_bytes = (0, 0, 56)  # device pass: bytes per sample, per record, per output row (SURVEY 8d)
     depends_on = []  # dynamic, see resolve_depends_on
     description = "Calculate rise/fall time based on peak detection results (HIP, gfx950)."
     version = "3.0.0+hip1"

@@ -13,10 +13,11 @@ from ..plugin_api import Option, Plugin
 from . import _common as K
 
 
-class HipWaveformWidthIntegralPlugin(Plugin):
+class HipWaveformWidthIntegralPlugin(K.HipPlugin):
     """Event-wise integral quantile width, computed on the GPU."""
 
     provides = "waveform_width_integral"
+    algorithmic_bytes = (2, 29 + 52, 0)  # device pass: bytes per sample, per record, per output row (SURVEY 8d)
     depends_on = []
     description = "Event-wise integral quantile width from records + wave_pool (HIP, gfx950)."
     version = "2.7.0+hip1"

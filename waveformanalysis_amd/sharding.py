@@ -7,8 +7,8 @@ dealt to it, packed into its own contiguous wave_pool.  The only exchange is the
 (record index, start sample) -- waveform_analysis/core/plugins/builtin/cpu/hit_finder.py:354-366 --
 before `group_hit_windows` (core/processing/event_grouping.py:286-471) consumes them.
 
-The gather itself is pluggable: `DeviceSession.rccl_gather_rows` (RCCL over xGMI, device-resident
-rows) on GPUs, `gather_rows_torch` (any torch.distributed backend, used by the CPU `gloo` tests).
+The gather is `DeviceSession.rccl_gather_rows` (RCCL over xGMI, device-resident rows); the CPU tests of the
+sharding logic bring their own transport (tests/dist_util.py: torch.distributed / gloo).
 """
 
 from __future__ import annotations
@@ -80,27 +80,4 @@ def merge_rows(rows_by_rank: list[np.ndarray], orig_index_by_rank: list[np.ndarr
     return rows[np.argsort(key, kind="stable")]
 
 
-def gather_rows_torch(rows: np.ndarray, root: int = 0):
-    """Gather structured rows with torch.distributed (gloo on CPU / nccl = RCCL on GPU).
-    Returns the list of per-rank arrays on `root`, None elsewhere.  Same two steps as the RCCL leg
-    of the C ABI: a count all-gather, then padded byte payloads."""
-    import torch
-    import torch.distributed as dist
-
-    world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([len(rows)], dtype=torch.int64))
-    counts = [int(c.item()) for c in counts]
-    item = rows.dtype.itemsize
-    width = max(counts) * item
-    payload = torch.zeros(max(width, 1), dtype=torch.uint8)
-    if len(rows):
-        payload[: len(rows) * item] = torch.from_numpy(np.frombuffer(rows.tobytes(), dtype=np.uint8).copy())
-    out = [torch.zeros_like(payload) for _ in range(world)] if rank == root else None
-    dist.gather(payload, out, dst=root)
-    if rank != root:
-        return None
-    return [np.frombuffer(out[r].numpy().tobytes()[: counts[r] * item], dtype=rows.dtype).copy() for r in range(world)]
-
-
-__all__ = ["channel_assignment", "Shard", "make_shard", "merge_rows", "gather_rows_torch"]
+__all__ = ["channel_assignment", "Shard", "make_shard", "merge_rows"]

@@ -428,46 +428,58 @@ class HipThresholdHitStream(HipStreamingPlugin):
             self._stage(sess, chunk, wave_pool)
             return self._collect(sess, chunk, run_id)
 
-    def _pipeline(self, input_chunks, context: Any, run_id: str, timeline: list | None = None):
-        """(input chunk, raw result) pairs in input order.  One host thread drives two sessions (two HIP streams, two
-        device pools) as a double buffer: while the kernels of chunk k run on one session, chunk k + 1 is uploaded
-        through the other session's pinned staging ring; nobody waits for chunk k before chunk k + 1 is queued.
-        `timeline` (optional) receives (k, t_stage_begin, t_queued, t_collected) host times per chunk."""
+    def _pipeline(self, input_chunks, context: Any, run_id: str, timeline: list | None = None,
+                  max_workers: int | None = None):
+        """(input chunk, raw result) pairs in input order.  One host thread drives a ring of sessions -- two per device
+        of the pool (each its own HIP stream and device buffers), so chunk k runs on device k mod n_devices: while the
+        kernels of chunks k - n + 1 .. k run, chunk k + 1 is uploaded through the next session's pinned staging ring;
+        nobody waits for chunk k before chunk k + 1 is queued.  `max_workers` (the reference's executor knob,
+        streaming.py:740-860) caps the ring.  `timeline` (optional) receives (k, t_stage_begin, t_queued, t_collected)
+        host times per chunk."""
         import time
+        from collections import deque
 
         self._configure(context)
         wave_pool = context.get_data(run_id, "wave_pool")
         pool = self._pool(context)
-        with pool.borrow() as s0, pool.borrow() as s1:
-            pending = None  # (k, chunk, session, stamps) of the chunk whose kernels are running
+        n = max(2, 2 * len(pool.device_ids))
+        if max_workers:
+            n = max(2, min(n, int(max_workers)))
+        n = min(n, pool.max_sessions)
+        if n < 2:
+            raise ValueError("the streaming hit pipeline needs a device pool with max_sessions >= 2")
+        with pool.borrow_many(n) as ring:
+            pending: deque = deque()  # (k, chunk, session, stamps) of the chunks whose kernels are queued, oldest first
 
             def finish():
-                pk, pchunk, ps, stamps = pending
+                pk, pchunk, ps, stamps = pending.popleft()
                 result = self._collect(ps, pchunk, run_id)
                 if timeline is not None:
                     timeline.append((pk, *stamps, time.perf_counter()))
                 return pchunk, result
 
+            staged = 0
             for k, chunk in enumerate(input_chunks):
                 if len(chunk.data) == 0:
-                    if pending is not None:
+                    while pending:
                         yield finish()
-                        pending = None
                     yield chunk, self._empty(chunk, run_id)
                     continue
-                sess = s1 if pending is not None and pending[2] is s0 else s0
+                sess = ring[staged % n]  # free: results are collected in order, at most n - 1 are pending here
+                staged += 1
                 t0 = time.perf_counter()
                 self._stage(sess, chunk, wave_pool)
                 t1 = time.perf_counter()
-                if pending is not None:
+                pending.append((k, chunk, sess, (t0, t1)))
+                while len(pending) > n - 1:
                     yield finish()
-                pending = (k, chunk, sess, (t0, t1))
-            if pending is not None:
+            while pending:
                 yield finish()
 
     def _compute_parallel(self, input_chunks, context: Any, run_id: str, executor_config: dict | None = None, **kwargs):
         """streaming.py:740-860, with the device pool in the place of the executor."""
-        for chunk, raw in self._pipeline(input_chunks, context, run_id):
+        workers = (executor_config or {}).get("max_workers") or self.max_workers
+        for chunk, raw in self._pipeline(input_chunks, context, run_id, max_workers=workers):
             result = self._postprocess_result(raw, chunk)
             if result is not None:
                 self._validate_chunk(result)
@@ -478,7 +490,7 @@ class HipThresholdHitStream(HipStreamingPlugin):
         """The raw results of `chunks`, in order (the bench and the parity tests call this with ready-made chunks)."""
         if not self.parallel or max_workers <= 1 or len(chunks) <= 1:
             return [self.compute_chunk(c, context, run_id) for c in chunks]
-        return [raw for _chunk, raw in self._pipeline(chunks, context, run_id, timeline)]
+        return [raw for _chunk, raw in self._pipeline(chunks, context, run_id, timeline, max_workers=max_workers)]
 
 
 __all__ = ["Chunk", "records_to_chunks", "HipStreamingPlugin", "HipThresholdHitStream"]
