@@ -124,8 +124,25 @@ def cpu_baseline(records, pool, n_records: int) -> dict:
     }
 
 
+def csrc_digest(repo: str = REPO) -> str:
+    """First 16 hex digits of the sha256 over the kernel sources (csrc/*.hip, *.hpp, include/wfa_hip.h, in name order): what
+    a PMC capture in profiles/hbm_traffic.json was taken from.  (The GPU box has no .git to ask.)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(repo, "waveformanalysis_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(repo, "waveformanalysis_amd", "csrc", "*.hpp")) +
+                   [os.path.join(repo, "include", "wfa_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_entry(kname: str, preset: str, n_records: int, L: int):
-    """HBM bytes per launch of `kname` on exactly this workload, from the PMC capture under profiles/ (or None)."""
+    """HBM bytes per launch of `kname` on exactly this workload, from the PMC capture under profiles/ -- or None when there
+    is none, or when the kernel sources have changed since it was taken (the entry's `csrc_sha16`)."""
     path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     try:
         table = json.load(open(path))
@@ -134,7 +151,12 @@ def traffic_entry(kname: str, preset: str, n_records: int, L: int):
     ent = table.get(f"{kname}|{preset}|{n_records}|{L}")
     if not isinstance(ent, dict):
         return None, None
-    return ent.get("bytes"), {k: ent.get(k) for k in ("fetch_bytes", "write_bytes", "commit", "source")}
+    src = {k: ent.get(k) for k in ("fetch_bytes", "write_bytes", "commit", "csrc_sha16", "source")}
+    now = csrc_digest()
+    if ent.get("csrc_sha16") != now:
+        src["stale"] = f"kernel sources are {now} now: capture again (tools/collect_hbm_traffic.sh)"
+        return None, src
+    return ent.get("bytes"), src
 
 
 def rank_main(args: argparse.Namespace) -> int:

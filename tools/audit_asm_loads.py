@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Audit of the hand-placed load pipeline of k_sg_runs32 in hipcc's assembly output (-save-temps).
+"""Audit of the hand-written assembly inside k_sg_runs32 in hipcc's assembly output (-save-temps).
 
 The tile loads are issued from inline asm; hipcc believes their destination registers are written when the statement
 ends.  Between an issue and the counted wait that names the same registers, no other instruction may touch them (a copy
 or spill there would read registers whose loads have not landed), and the kernel must not spill vector registers at all.
-Exit status 1 with the offending lines if that does not hold."""
+The kernel also places one VALU instruction by hand (`v_mad_i32_i16`, the first tap of every numerator).  gfx950 needs wait
+states between a dot instruction (v_dot*) and a DIFFERENT vector instruction that reads its result; hipcc pads the
+instructions it schedules itself but knows nothing about the operands of inline assembly (an inline
+v_dot2 in that place gave nondeterministic results).  So: no inline vector instruction may read a register that a v_dot*
+wrote within the last kHazardWindow instructions.
+Exit status 1 with the offending lines if any of this does not hold."""
 import re
 import sys
 
@@ -17,6 +22,41 @@ def regs_of(text: str) -> set:
         else:
             out.update(range(int(m.group(1)), int(m.group(2)) + 1))
     return out
+
+
+kHazardWindow = 4  # instructions (more than the wait states any dot -> VALU dependency needs)
+
+
+def dot_hazards(name: str, lines: list) -> int:
+    """Inline-asm vector instructions whose sources were written by a v_dot* just before them."""
+    bad = 0
+    recent = []  # (line number, text, registers written) of the last few instructions
+    in_asm = False
+    for k, raw in enumerate(lines):
+        ln = raw.strip()
+        if ";;#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in ln:
+            in_asm = False
+            continue
+        code = ln.split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        ops = code.split(None, 1)
+        operands = [o.strip() for o in ops[1].split(",")] if len(ops) > 1 else [""]
+        dst = regs_of(operands[0]) if ops[0].startswith("v_") else set()
+        if in_asm and ops[0].startswith("v_"):
+            src = set()
+            for o in operands[1:]:
+                src |= regs_of(o)
+            for (kk, text, written) in recent:
+                if text.startswith("v_dot") and written & src:
+                    print(f"{name}: line {k}: inline `{code}` reads the result of `{text}` (line {kk}) inside the dot hazard window")
+                    bad += 1
+        recent.append((k, code, dst))
+        recent = recent[-kHazardWindow:]
+    return bad
 
 
 def main(path: str, prefix: str = r"_ZN3wfa11k_sg_runs32") -> int:
@@ -33,6 +73,7 @@ def main(path: str, prefix: str = r"_ZN3wfa11k_sg_runs32") -> int:
             print(f"{name}: vector register spills ({m.group(0)})")
             bad += 1
         lines = fn.split("\n")
+        bad += dot_hazards(name, lines)
         i = 0
         while i < len(lines):
             if ";;#ASMSTART" in lines[i]:
