@@ -359,10 +359,19 @@ def rank_main(args: argparse.Namespace) -> int:
             plugin = HipThresholdHitPlugin()
             t1 = time.perf_counter()
             rows = plugin.compute(ctx, "bench")
+            first = time.perf_counter() - t1
+            # second call on the same thread's session (device buffers and the pinned ring exist); the pool is another
+            # array object, so everything is uploaded again
+            ctx2 = SimpleContext(dict(ctx.config), {"records": rec_in, "wave_pool": pool.copy()})
+            ctx2.wfa_device_pool = None
+            t1 = time.perf_counter()
+            rows = plugin.compute(ctx2, "bench")
             dt = time.perf_counter() - t1
-            e2e = {"value": round(n_samples / dt / 1e9, 3), "unit": "Gsamples/s", "seconds": round(dt, 3),
-                   "rows": int(len(rows)), "what": "HipThresholdHitPlugin.compute: H2D of pool + records (pinned staging "
-                   "ring), fused pass, D2H of the hit rows"}
+            e2e = {"value": round(n_samples / dt / 1e9, 3), "unit": "Gsamples/s", "seconds": round(dt, 4),
+                   "first_call_seconds": round(first, 4),
+                   "rows": int(len(rows)), "what": "HipThresholdHitPlugin.compute: H2D of pool + packed record rows (pinned "
+                   "staging ring), records unpacked on the device, fused pass, D2H of the hit rows; first_call_seconds "
+                   "includes creating the session, its device buffers and the pinned ring"}
         except Exception as exc:  # noqa: BLE001
             e2e = {"error": f"{type(exc).__name__}: {exc}"}
 

@@ -108,6 +108,21 @@ int wfa_upload_records_soa(wfa_ctx* ctx, int64_t n_records,
                            const int32_t* dt_ns, const int16_t* board, const int16_t* channel,
                            const int64_t* record_id);
 
+/* The same table as packed rows, unpacked ON THE DEVICE: `rows` = n_records rows of row_bytes bytes exactly as a numpy
+ * structured array holds them (reference RECORDS_DTYPE, core/processing/dtypes.py:80-100: 102 bytes, unaligned).
+ * field_offsets[9] = byte offset inside a row of wave_offset (int64), event_length (int32), baseline (float64), polarity
+ * (UCS-4 text of polarity_chars characters: "negative" / "positive" / anything else = unknown, as
+ * data/records_view.py:87-100 reads it), timestamp (int64), dt (int32), board (int16), channel (int16), record_id (int64);
+ * -1 for an absent polarity / dt / board / channel (defaults unknown / 1 / 0 / 0).  `threshold` applies to every record
+ * unless `thresholds` (nullable, one float64 per record: hit_finder.py:288-327 resolved by the caller) is given;
+ * `polarity` (nullable, one WFA_POL_* code per record) overrides the text field.  Same validation and messages as the
+ * column route.  *record_ids_increasing = 0 tells the caller that record_id is not strictly increasing (it then has to
+ * check uniqueness itself: records_view.py:383-400); *max_len = longest record. */
+int wfa_upload_records_packed(wfa_ctx* ctx, const void* rows, int64_t n_records, int32_t row_bytes,
+                              const int32_t* field_offsets, int32_t polarity_chars, double threshold,
+                              const double* thresholds, const int8_t* polarity, int32_t* max_len,
+                              int* record_ids_increasing);
+
 /* Savitzky-Golay plan (reference: cpu/filtering.py:181-195,226-240 + scipy.signal.savgol_filter
  * mode="interp").  Tables are built on the host (waveformanalysis_amd/sg_plan.py):
  *   n_tables = (window+1)/2; table t serves effective window w = 2t+1 (short records,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "wfa_upload_pool_u16": (_int, [_p, _p, _i64]),
     "wfa_upload_pool_f32": (_int, [_p, _p, _i64]),
     "wfa_upload_records_soa": (_int, [_p, _i64] + [_p] * 10),
+    "wfa_upload_records_packed": (_int, [_p, _p, _i64, _i32, _p, _i32, _f64, _p, _p, C.POINTER(_i32), C.POINTER(_int)]),
     "wfa_set_sg_plan": (_int, [_p, _int, _int, _p, _p, _int, _p, _i32, _i32, _i64, _i64]),
     "wfa_baseline_mean": (_int, [_p, _i32, _i32, _int, _p]),
     "wfa_filter_keep_output": (_int, [_p, _int]),

@@ -592,6 +592,91 @@ static int run_hits(wfa_ctx* c, int source, bool fused_bl, int32_t bl_start, int
 
 using namespace wfa;
 
+// ---- records as packed rows, unpacked on the device --------------------------------------------------------------------
+// (reference row layout: processing/dtypes.py:80-100, 102 bytes, numpy packs without alignment.)  The column route above
+// makes the caller extract ten columns on the host -- for 1.25e6 records that is 0.6 s of numpy, 0.47 s of it comparing
+// the 32-byte `polarity` strings -- before 1 ms of GPU work.  Here the rows go through the pinned staging ring as they are
+// (128 MB: 3 ms) and one kernel writes the columns, validates them and finds what the host loop above finds.
+struct PackedFields {  // byte offsets inside a row; -1 = field absent (default used)
+    int32_t off, len, baseline, polarity, ts, dt, board, chan, rid;
+    int32_t polarity_chars;  // width of the UCS-4 polarity field in characters (>= 8)
+    int32_t row_bytes;
+};
+struct UnpackResult {  // one per upload, device -> host
+    unsigned long long first_bad[4];  // first record with: negative offset, negative length, out of pool, too long
+    int max_len;
+    int nonuniform;       // some record breaks (len == len0, off == off0 + r len0, polarity class == class 0)
+    int rid_not_increasing;
+    int pad;
+};
+
+template <typename T>
+__device__ __forceinline__ T load_unaligned(const uint8_t* p) {
+    T v;
+    uint8_t b[sizeof(T)];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T); ++i) b[i] = p[i];
+    __builtin_memcpy(&v, b, sizeof(T));
+    return v;
+}
+
+__device__ __forceinline__ bool ucs4_equals(const uint8_t* p, int chars, const char* word) {  // `word` has 8 letters
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) eq = eq && load_unaligned<uint32_t>(p + 4 * i) == (uint32_t)(unsigned char)word[i];
+    if (chars > 8) eq = eq && load_unaligned<uint32_t>(p + 32) == 0u;
+    return eq;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_records(const uint8_t* __restrict__ rows, int64_t R, PackedFields f,
+                                                         int64_t pool_n, double thr_scalar, const double* __restrict__ thr_in,
+                                                         const int8_t* __restrict__ pol_in, RecView out_cols,
+                                                         int8_t* __restrict__ out_pol, double* __restrict__ out_thr,
+                                                         int64_t* __restrict__ out_off, int32_t* __restrict__ out_len,
+                                                         int64_t* __restrict__ out_ts, int32_t* __restrict__ out_dt,
+                                                         int16_t* __restrict__ out_board, int16_t* __restrict__ out_chan,
+                                                         int64_t* __restrict__ out_rid, int32_t* __restrict__ bm_bytes,
+                                                         UnpackResult* __restrict__ res) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const uint8_t* row = rows + r * f.row_bytes;
+    const int64_t off = load_unaligned<int64_t>(row + f.off);
+    const int32_t len = load_unaligned<int32_t>(row + f.len);
+    auto pol_of = [&](const uint8_t* rw) -> int8_t {
+        if (f.polarity < 0) return WFA_POL_UNKNOWN;
+        if (ucs4_equals(rw + f.polarity, f.polarity_chars, "negative")) return WFA_POL_NEGATIVE;
+        if (ucs4_equals(rw + f.polarity, f.polarity_chars, "positive")) return WFA_POL_POSITIVE;
+        return WFA_POL_UNKNOWN;
+    };
+    const int8_t pol = pol_in ? pol_in[r] : pol_of(row);
+    const int64_t rid = load_unaligned<int64_t>(row + f.rid);
+    out_off[r] = off;
+    out_len[r] = len;
+    out_cols.baseline_rw[r] = load_unaligned<double>(row + f.baseline);
+    out_pol[r] = pol;
+    out_thr[r] = thr_in ? thr_in[r] : thr_scalar;
+    out_ts[r] = load_unaligned<int64_t>(row + f.ts);
+    out_dt[r] = f.dt >= 0 ? load_unaligned<int32_t>(row + f.dt) : 1;
+    out_board[r] = f.board >= 0 ? load_unaligned<int16_t>(row + f.board) : (int16_t)0;
+    out_chan[r] = f.chan >= 0 ? load_unaligned<int16_t>(row + f.chan) : (int16_t)0;
+    out_rid[r] = rid;
+    bm_bytes[r] = (int32_t)(((int64_t)(len > 0 ? len : 0) + 7 + 63) / 64 * 8 + 8);
+    // the checks of the column route, first offender per kind (the host reports the earliest one)
+    if (off < 0) atomicMin(&res->first_bad[0], (unsigned long long)r);
+    if (len < 0) atomicMin(&res->first_bad[1], (unsigned long long)r);
+    if (off >= 0 && len >= 0 && off + (int64_t)len > pool_n) atomicMin(&res->first_bad[2], (unsigned long long)r);
+    if (len > WFA_MAX_RECORD_SAMPLES) atomicMin(&res->first_bad[3], (unsigned long long)r);
+    if (len > 0) atomicMax(&res->max_len, len);
+    // uniform layout (span mode / padded shadow): against record 0, read again by every thread (one cached line)
+    const int64_t off0 = load_unaligned<int64_t>(rows + f.off);
+    const int32_t len0 = load_unaligned<int32_t>(rows + f.len);
+    const int8_t pol0 = pol_in ? pol_in[0] : pol_of(rows);
+    if (len != len0 || off != off0 + r * (int64_t)len0 || (pol == WFA_POL_POSITIVE) != (pol0 == WFA_POL_POSITIVE))
+        atomicOr(&res->nonuniform, 1);
+    if (r > 0 && rid <= load_unaligned<int64_t>(row - f.row_bytes + f.rid)) atomicOr(&res->rid_not_increasing, 1);
+}
+
+
 extern "C" {
 
 int wfa_abi_version(void) { return WFA_ABI_VERSION; }
@@ -825,6 +910,112 @@ int wfa_upload_records_soa(wfa_ctx* c, int64_t R, const int64_t* off, const int3
     c->no_runs32 = false;
     c->have_records = true;
     c->n_hits = -1;
+    return WFA_OK;
+}
+
+
+int wfa_upload_records_packed(wfa_ctx* c, const void* rows, int64_t R, int32_t row_bytes, const int32_t* field_offsets,
+                              int32_t polarity_chars, double threshold, const double* thresholds, const int8_t* polarity,
+                              int32_t* max_len_out, int* record_ids_increasing) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (!c->have_u16 && !c->have_f32) return fail(WFA_E_STATE, "upload a pool before the records");
+    if (R < 0) return fail(WFA_E_INVALID, "negative record count");
+    if (row_bytes <= 0 || !field_offsets || (R > 0 && !rows)) return fail(WFA_E_INVALID, "bad packed rows");
+    PackedFields f{};
+    int32_t* fo = &f.off;
+    // order: wave_offset, event_length, baseline, polarity, timestamp, dt, board, channel, record_id
+    const int32_t width[9] = {8, 4, 8, 4 * polarity_chars, 8, 4, 2, 2, 8};
+    const bool required[9] = {true, true, true, false, true, false, false, false, true};
+    for (int k = 0; k < 9; ++k) {
+        fo[k] = field_offsets[k];
+        if (fo[k] < 0 && required[k]) return fail(WFA_E_INVALID, "packed rows lack a required field (index %d)", k);
+        if (fo[k] >= 0 && fo[k] + width[k] > row_bytes) return fail(WFA_E_INVALID, "field %d does not fit a %d-byte row", k, row_bytes);
+    }
+    if (f.polarity >= 0 && polarity_chars < 8) f.polarity = -1;  // neither "negative" nor "positive" fits: always unknown
+    f.polarity_chars = polarity_chars;
+    f.row_bytes = row_bytes;
+    const size_t n = (size_t)R;
+    if ((rc = c->off.ensure(n * 8)) || (rc = c->len.ensure(n * 4)) || (rc = c->baseline.ensure(n * 8)) || (rc = c->pol.ensure(n)) ||
+        (rc = c->thr.ensure(n * 8)) || (rc = c->ts.ensure(n * 8)) || (rc = c->dt.ensure(n * 4)) || (rc = c->board.ensure(n * 2)) ||
+        (rc = c->chan.ensure(n * 2)) || (rc = c->rid.ensure(n * 8)) || (rc = c->bm_off.ensure(n * 8)))
+        return rc;
+    c->have_records = false;
+    c->R = 0;
+    int32_t max_len = 0;
+    bool increasing = true;
+    c->span_ok = c->pad_ok = false;
+    c->shadow_valid = false;
+    c->bitmap_bytes = 64;
+    if (R > 0) {
+        // scratch: the rows, per-record bitmap bytes, the optional per-record columns of the caller, the result block
+        DevBuf d_rows, d_bm, d_thr, d_pol, d_res, d_blocks;
+        const int64_t nb = scan_blocks_for(R);
+        if ((rc = h2d(c, d_rows, rows, n * (size_t)row_bytes))) return rc;
+        if ((rc = d_bm.ensure(n * 4)) || (rc = d_res.ensure(sizeof(UnpackResult))) || (rc = d_blocks.ensure((size_t)(nb + 1) * 8))) return rc;
+        if (thresholds && (rc = h2d(c, d_thr, thresholds, n * 8))) return rc;
+        if (polarity && (rc = h2d(c, d_pol, polarity, n))) return rc;
+        UnpackResult init{};
+        for (auto& x : init.first_bad) x = ~0ull;
+        WFA_HIP_CHECK(hipMemcpyAsync(d_res.ptr, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        RecView cols{};
+        cols.baseline_rw = c->baseline.as<double>();
+        {
+            LaunchTimer t(c);
+            hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream,
+                               d_rows.as<uint8_t>(), R, f, c->pool_n, threshold, thresholds ? d_thr.as<double>() : nullptr,
+                               polarity ? d_pol.as<int8_t>() : nullptr, cols, c->pol.as<int8_t>(), c->thr.as<double>(),
+                               c->off.as<int64_t>(), c->len.as<int32_t>(), c->ts.as<int64_t>(), c->dt.as<int32_t>(),
+                               c->board.as<int16_t>(), c->chan.as<int16_t>(), c->rid.as<int64_t>(), d_bm.as<int32_t>(),
+                               d_res.as<UnpackResult>());
+            WFA_HIP_CHECK(hipGetLastError());
+            WFA_HIP_CHECK(launch_scan(c->stream, d_bm.as<int32_t>(), R, d_blocks.as<int64_t>(), c->bm_off.as<int64_t>()));
+            if ((rc = t.end("k_unpack_records + bitmap offsets"))) return rc;
+        }
+        UnpackResult res{};
+        int64_t bm_total = 0;
+        int64_t first[2] = {0, 0};
+        int32_t len0 = 0;
+        int8_t pol0 = 0;
+        WFA_HIP_CHECK(hipMemcpyAsync(&res, d_res.ptr, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipMemcpyAsync(&bm_total, d_blocks.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipMemcpyAsync(&first[0], c->off.ptr, 8, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipMemcpyAsync(&len0, c->len.ptr, 4, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipMemcpyAsync(&pol0, c->pol.ptr, 1, hipMemcpyDeviceToHost, c->stream));
+        WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+        // the earliest offending record decides, its checks in the order of the column route (records_view.py:47-56)
+        unsigned long long worst = ~0ull;
+        for (auto x : res.first_bad) worst = x < worst ? x : worst;
+        if (worst != ~0ull) {
+            if (res.first_bad[0] == worst) return fail(WFA_E_INVALID, "records contain negative wave_offset values");
+            if (res.first_bad[1] == worst) return fail(WFA_E_INVALID, "records contain negative event_length values");
+            if (res.first_bad[2] == worst) return fail(WFA_E_INVALID, "records reference samples outside wave_pool bounds");
+            return fail(WFA_E_LIMIT, "record %lld has more samples than this build supports (at most %d)", (long long)worst,
+                        WFA_MAX_RECORD_SAMPLES);
+        }
+        if (polarity) {  // caller's codes: range-checked like the column route (the kernel only compared them)
+            for (int64_t r = 0; r < R; ++r)
+                if (polarity[r] < WFA_POL_UNKNOWN || polarity[r] > WFA_POL_POSITIVE_WAVE)
+                    return fail(WFA_E_INVALID, "bad polarity code %d at record %lld", (int)polarity[r], (long long)r);
+        }
+        max_len = res.max_len;
+        increasing = res.rid_not_increasing == 0;
+        c->bitmap_bytes = bm_total + 64;
+        const bool uniform = res.nonuniform == 0;
+        c->span_ok = uniform && len0 >= 24 && (len0 % 8) == 0 && (first[0] % 8) == 0;
+        if (c->span_ok) { c->span_L = len0; c->span_off0 = first[0]; c->span_positive = pol0 == WFA_POL_POSITIVE; }
+        c->pad_ok = uniform && c->have_u16 && len0 >= 32 && (len0 % 16) != 0;
+        if (c->pad_ok) { c->pad_L = len0; c->pad_S = (len0 + 15) / 16 * 16; c->pad_off0 = first[0]; c->pad_positive = pol0 == WFA_POL_POSITIVE; }
+    }
+    c->bitmap_clean = false;
+    c->R = R;
+    c->max_len = max_len;
+    c->pw_plan_n = -1;
+    c->no_runs32 = false;
+    c->have_records = true;
+    c->n_hits = -1;
+    if (max_len_out) *max_len_out = max_len;
+    if (record_ids_increasing) *record_ids_increasing = increasing ? 1 : 0;
     return WFA_OK;
 }
 

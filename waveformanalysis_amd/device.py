@@ -155,19 +155,65 @@ class DeviceSession:
         _lib.check(self._lib.wfa_upload_pool_f32(self._h, _ptr(arr), arr.size))
         self.uploads += 1
 
+    packed_records = True  # False: always the column route (tests compare the two)
+    _PACKED_FIELDS = (("wave_offset", "<i8", True), ("event_length", "<i4", True), ("baseline", "<f8", True),
+                      ("polarity", "U", False), ("timestamp", "<i8", True), ("dt", "<i4", False), ("board", "<i2", False),
+                      ("channel", "<i2", False), ("record_id", "<i8", True))
+
+    @classmethod
+    def _packed_layout(cls, records: np.ndarray):
+        """(field byte offsets, polarity width in characters) when the structured array can go to the device as it is:
+        one contiguous block of rows whose fields have the reference's types (core/processing/dtypes.py:80-100); None
+        for anything else (views with gaps, other integer widths, byte strings, ...): the column route takes those."""
+        dt = records.dtype
+        if not (records.flags.c_contiguous and records.ndim == 1 and records.strides == (dt.itemsize,)):
+            return None
+        offsets, pol_chars = [], 0
+        for name, kind, _required in cls._PACKED_FIELDS:
+            if name not in dt.fields:
+                offsets.append(-1)
+                continue
+            ftype, foff = dt.fields[name][0], dt.fields[name][1]
+            if kind == "U":
+                if ftype.kind != "U" or ftype.byteorder not in ("=", "<", "|"):
+                    return None
+                pol_chars = ftype.itemsize // 4
+            elif ftype.str != kind:
+                return None
+            offsets.append(int(foff))
+        return np.asarray(offsets, dtype=np.int32), pol_chars
+
     def upload_records(self, records: np.ndarray, thresholds: np.ndarray | float = 10.0,
                        polarity: np.ndarray | None = None) -> None:
-        """records -> device SoA.  `polarity`: optional int8 WFA_POL_* codes overriding records["polarity"]."""
+        """records -> device SoA.  `polarity`: optional int8 WFA_POL_* codes overriding records["polarity"].
+
+        A contiguous structured array with the reference's field types is copied to the device as packed rows and
+        unpacked there (wfa_upload_records_packed); anything else goes column by column (wfa_upload_records_soa)."""
         if records.dtype.names is None:
             raise ValueError("records must be a structured array")
         missing = [n for n in REQUIRED_RECORD_FIELDS if n not in records.dtype.names]
         if missing:
             raise ValueError(f"records missing required fields: {missing}")
         n = len(records)
+        layout = self._packed_layout(records) if self.packed_records else None
+        if layout is not None:
+            offsets, pol_chars = layout
+            thr = np.asarray(thresholds, dtype=np.float64)
+            thr_arr = None if thr.ndim == 0 else np.ascontiguousarray(np.broadcast_to(thr, (n,)))
+            pol_arr = None if polarity is None else np.ascontiguousarray(polarity, dtype=np.int8)
+            if pol_arr is not None and pol_arr.shape != (n,):
+                raise ValueError("polarity must hold one code per record")
+            max_len, increasing = C.c_int32(0), C.c_int(1)
+            _lib.check(self._lib.wfa_upload_records_packed(
+                self._h, _ptr(records), n, records.dtype.itemsize, _ptr(offsets), int(pol_chars),
+                float(thr) if thr.ndim == 0 else 0.0, _ptr(thr_arr), _ptr(pol_arr), C.byref(max_len), C.byref(increasing)))
+            if not increasing.value:  # rare: ids out of order -- uniqueness the way the column route checks it
+                self._check_unique_ids(np.ascontiguousarray(records["record_id"], dtype=np.int64))
+            self.n_records = n
+            self.max_len = int(max_len.value)
+            return
         rid = _col(records, "record_id", np.int64)
-        if n and len(np.unique(rid)) != n:
-            dup = rid[np.flatnonzero(np.diff(np.sort(rid)) == 0)[0]] if n > 1 else rid[0]
-            raise ValueError(f"records field record_id must be unique, got duplicate {int(dup)}")
+        self._check_unique_ids(rid)
         thr = np.ascontiguousarray(np.broadcast_to(np.asarray(thresholds, dtype=np.float64), (n,)))
         cols = [
             _col(records, "wave_offset", np.int64),
@@ -184,6 +230,14 @@ class DeviceSession:
         _lib.check(self._lib.wfa_upload_records_soa(self._h, n, *[_ptr(c) for c in cols]))
         self.n_records = n
         self.max_len = int(cols[1].max()) if n else 0
+
+    @staticmethod
+    def _check_unique_ids(rid: np.ndarray) -> None:
+        n = len(rid)
+        if n and len(np.unique(rid)) != n:
+            ordered = np.sort(rid)
+            dup = ordered[np.flatnonzero(np.diff(ordered) == 0)[0]]
+            raise ValueError(f"records field record_id must be unique, got duplicate {int(dup)}")
 
     def set_sg_plan(self, sg_window_size: int = 11, sg_poly_order: int = 2) -> SgPlan:
         plan = build_plan(int(sg_window_size), int(sg_poly_order))

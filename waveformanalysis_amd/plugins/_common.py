@@ -15,7 +15,7 @@ from typing import Any
 import numpy as np
 
 from .. import _lib
-from ..channel_config import per_record_option, scatter_per_record
+from ..channel_config import per_record_option, resolve_channel_values, scatter_per_record
 from ..device import DeviceSession, default_pool
 from ..plugin_api import Plugin
 
@@ -166,17 +166,23 @@ def require_dt_array(data: np.ndarray, *, explicit_dt: Any, plugin_name: str, da
 
 def per_record_channel_option(records: np.ndarray, channel_config: Any, run_id: str, name: str,
                               base_value: Any, default: float) -> np.ndarray:
-    """Resolve one option per (board, channel) and scatter it to a per-record float64 array."""
+    """Resolve one option per (board, channel) and scatter it to a per-record float64 array (a 0-d array when there is
+    no per-channel configuration: every record gets the base value, nothing per record happens on the host)."""
+    if not channel_config:
+        return np.asarray(default if base_value is None else float(base_value), dtype=np.float64)
     n = len(records)
     names = records.dtype.names or ()
     boards = records["board"] if "board" in names else np.zeros(n, dtype=np.int16)
     channels = records["channel"] if "channel" in names else np.zeros(n, dtype=np.int16)
-    per = per_record_option(boards, channels, channel_config, run_id, {name: base_value})
-    values = {}
-    for key, rule in per.items():
-        v = rule.get(name, base_value)
-        values[key] = default if v is None else float(v)
-    return scatter_per_record(boards, channels, values, default)
+    # one sort of a 64-bit key instead of a row-wise unique + one mask per channel
+    key = np.asarray(boards, dtype=np.int64) * 65536 + (np.asarray(channels, dtype=np.int64) & 0xFFFF)
+    uniq, inverse = np.unique(key, return_inverse=True)
+    values = np.empty(len(uniq), dtype=np.float64)
+    for k, kv in enumerate(uniq):
+        b, c = int(kv >> 16), int(np.int16(np.uint16(kv & 0xFFFF)))
+        v = resolve_channel_values(channel_config, run_id, b, c, {name: base_value}).get(name, base_value)
+        values[k] = default if v is None else float(v)
+    return values[inverse.reshape(-1)]
 
 
 # ---- residency: keep the pool of a run on the GPU between plugin calls -----------------------------
