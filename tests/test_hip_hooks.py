@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def test_profiler_keys_rates_and_cleanup_on_the_device():
     rec, pool = synth.make_run(4000, "vx2730", cfg=12)
-    ctx = SimpleContext({"wave_source": "records", "use_filtered": True, "fuse_filter": True},
+    ctx = SimpleContext({"wave_source": "records", "hit_threshold": {"use_filtered": True, "fuse_filter": True}},
                         {"records": rec, "wave_pool": pool}, [HipThresholdHitPlugin(), HipBasicFeaturesPlugin()])
     ctx.profiler, ctx.stats_collector = Profiler(), Stats()
     ctx.wfa_device_pool = DevicePool([0])
