@@ -57,6 +57,8 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threshold", type=float, default=10.0, help="hit threshold (reference default 10.0)")
     ap.add_argument("--no-features", action="store_true", help="skip the untimed feature / filter / end-to-end extras")
+    ap.add_argument("--c4-records", type=int, default=333_334,
+                    help="N > 1 only: records per GPU of the untimed config-4 leg (256-ch VX2730, x1500 = 5e8 samples); 0 = skip")
     ap.add_argument("--master-port", type=int, default=int(os.environ.get("WFA_BENCH_PORT", "29613")))
     return ap.parse_args()
 
@@ -157,6 +159,83 @@ def traffic_entry(kname: str, preset: str, n_records: int, L: int):
         src["stale"] = f"kernel sources are {now} now: capture again (tools/collect_hbm_traffic.sh)"
         return None, src
     return ent.get("bytes"), src
+
+
+def row_digest(rows) -> tuple[int, int]:
+    """(count, 64-bit checksum) of a table of packed rows: the sum, modulo 2^64, of every row's 8-byte words (the tail of a
+    row zero-extended) each multiplied by an odd constant of its position in the row -- rows may arrive in any order."""
+    import numpy as np
+
+    n, width = len(rows), rows.dtype.itemsize
+    if n == 0:
+        return 0, 0
+    words = (width + 7) // 8
+    buf = np.zeros((n, words * 8), dtype=np.uint8)
+    buf[:, :width] = np.frombuffer(rows.tobytes(), dtype=np.uint8).reshape(n, width)
+    mult = (np.arange(words, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    with np.errstate(over="ignore"):
+        total = (buf.view(np.uint64) * mult[None, :]).sum(dtype=np.uint64)
+    return n, int(total)
+
+
+def config4_leg(args, DeviceSession, dist, rank: int, world: int, device_id: int) -> dict:
+    """BASELINE config 4 under N > 1, outside the timed region: a 256-channel VX2730 run dealt to the ranks by channel,
+    every rank its fused pass on the padded streaming route, all rows gathered over RCCL to rank 0, the gathered table
+    VERIFIED there against every rank's own digest of what it sent (count + checksum, exchanged over the gloo control
+    plane), then grouped from the device buffer (event_grouping.py:286-471)."""
+    import numpy as np
+    import torch
+
+    from waveformanalysis_amd import synth
+    from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
+
+    out: dict = {"preset": "vx2730", "channels": 256, "records_per_gpu": int(args.c4_records)}
+    rec4, pool4 = synth.make_run(args.c4_records, "vx2730", cfg=400 + rank)
+    # rank r owns the channels {c : c mod world == r} of the 8 x 32 = 256: every record of this rank lands on one of them
+    flat = rec4["board"].astype(np.int64) * 32 + rec4["channel"]
+    flat = (flat // world) * world % 256 + rank if world <= 256 else flat
+    rec4["board"], rec4["channel"] = flat // 32, flat % 32
+    rec4["baseline"] = np.nan
+    out["samples_per_gpu"] = int(pool4.size)
+    s4 = DeviceSession(device_id)
+    try:
+        s4.upload_pool(pool4)
+        s4.upload_records(rec4, args.threshold)
+        s4.set_sg_plan(11, 2)
+        n4 = s4.fused_baseline_filter_hits((0, synth.BASELINE_SAMPLES), 2, 2, download=False)
+        mine = s4._fill_hits(n4)
+        cnt, chk = row_digest(mine)
+        digests = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(digests, torch.tensor([cnt, chk - (1 << 64) if chk >= (1 << 63) else chk], dtype=torch.int64))
+        uid = [DeviceSession.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        s4.rccl_init(rank, world, uid[0])
+        s4.rccl_gather_rows(None, n4, THRESHOLD_HIT_DTYPE, root=0, download=False)  # connection setup
+        dist.barrier()
+        t1 = time.perf_counter()
+        counts, _none = s4.rccl_gather_rows(None, n4, THRESHOLD_HIT_DTYPE, root=0, download=False)
+        out["gather_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+        out["hits_total"] = int(counts.sum())
+        _counts, table = s4.rccl_gather_rows(None, n4, THRESHOLD_HIT_DTYPE, root=0, download=True)  # untimed: the check
+        if rank == 0:
+            ok, at = True, 0
+            for r in range(world):
+                want_n, want_chk = int(digests[r][0]), int(digests[r][1]) % (1 << 64)
+                got_n, got_chk = row_digest(table[at:at + int(counts[r])])
+                ok = ok and got_n == want_n == int(counts[r]) and got_chk == want_chk
+                at += int(counts[r])
+            out["verified"] = bool(ok and at == len(table))
+            s4.hit_rows_source("gather")
+            t2 = time.perf_counter()
+            flat_ev = s4.group_hit_windows_resident(out["hits_total"], 100.0)
+            out["group_hit_windows_ms"] = round((time.perf_counter() - t2) * 1e3, 3)
+            out["events"] = int(len(flat_ev["event_start"]) - 1)
+            boards = np.unique(table["board"].astype(np.int64) * 32 + table["channel"])
+            out["channels_seen"] = int(len(boards))
+        out["ok"] = True
+    finally:
+        s4.close()
+    return out
 
 
 def rank_main(args: argparse.Namespace) -> int:
@@ -286,6 +365,8 @@ def rank_main(args: argparse.Namespace) -> int:
                     box["group_ms"] = (time.perf_counter() - t2) * 1e3
                     box["events"] = int(len(flat["event_start"]) - 1)
                     sess.hit_rows_source("hits")
+                if args.c4_records > 0:
+                    box["c4"] = config4_leg(args, DeviceSession, dist, rank, world, device_id)
                 box["ok"] = True
             except Exception as exc:  # noqa: BLE001
                 box["note"] = f"{type(exc).__name__}: {exc}"
@@ -298,6 +379,12 @@ def rank_main(args: argparse.Namespace) -> int:
         gather = {"ok": gather_ok, "hung": hung, "ms": box.get("ms"), "hits_total": box.get("total"),
                   "group_hit_windows_ms": box.get("group_ms"), "events": box.get("events"), "note": box.get("note"),
                   "time_window_ns": 100.0, "rows": "device-resident on rank 0 (no host copy)"}
+        if box.get("c4") is not None:
+            gather["config4"] = box["c4"]
+            if rank == 0 and not box["c4"].get("verified", False):
+                gather_ok = False
+                gather["ok"] = False
+                gather["note"] = (gather.get("note") or "") + " config-4 table does not match the ranks' digests"
         if not hung:
             # every rank learns whether any rank failed, so that all exit with the same status
             import torch
@@ -318,6 +405,7 @@ def rank_main(args: argparse.Namespace) -> int:
             sess.profile(timed)
             sess.basic_features(L_.SRC_RAW)
             sess.width_integral(L_.SRC_RAW, dt=4.0)
+            sess.features_both(dt=4.0, download=False)  # both tables from one read of the pool (config 3)
             sess.savgol(download=False)
             # find_peaks hit detector on the filtered pool that savgol just left resident (reference defaults)
             n_peaks = len(sess.find_peaks(L_.SRC_F32))
@@ -340,11 +428,20 @@ def rank_main(args: argparse.Namespace) -> int:
         c3 = {"hits_pass_ms": round(pass_ms, 4),
               "k_basic_features_ms": extra_ms.get("k_basic_features_leaf", extra_ms.get("k_basic_features")),
               "k_width_integral_ms": extra_ms.get("k_width_integral_leaf", extra_ms.get("k_width_integral"))}
-        if c3["k_basic_features_ms"] is not None and c3["k_width_integral_ms"] is not None:
+        c3["k_features_both_ms"] = extra_ms.get("k_features_both_leaf")
+        if c3["k_features_both_ms"] is not None:
+            # records -> hits -> both feature tables: the fused pass + ONE feature kernel that reads the pool once
+            c3["total_ms"] = round(pass_ms + c3["k_features_both_ms"], 4)
+            c3["Gsamples_per_s"] = round(n_samples / c3["total_ms"] / 1e6, 1)
+            c3["algorithmic_bytes"] = int(2 * 2 * n_samples + (2 * 29 + 36 + 52) * len(records) + 60 * n_hits)
+            c3["frac"] = round(c3["algorithmic_bytes"] / (c3["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            c3["note"] = "two reads of the pool (hit pass, feature kernel); frac on 2 x 2 B/sample + record columns + rows"
+        elif c3["k_basic_features_ms"] is not None and c3["k_width_integral_ms"] is not None:
             c3["total_ms"] = round(pass_ms + c3["k_basic_features_ms"] + c3["k_width_integral_ms"], 4)
             c3["Gsamples_per_s"] = round(n_samples / c3["total_ms"] / 1e6, 1)
-            # stand-alone roofline of the two feature kernels: one read of the samples + the record columns + one row
-            for key, row_bytes in (("k_basic_features", 36), ("k_width_integral", 52)):
+        # stand-alone roofline of the feature kernels: one read of the samples + the record columns + their rows
+        for key, row_bytes in (("k_basic_features", 36), ("k_width_integral", 52), ("k_features_both", 36 + 52)):
+            if c3.get(key + "_ms") is not None:
                 b = 2 * n_samples + (29 + row_bytes) * len(records)
                 c3[key + "_frac"] = round(b / (c3[key + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # end to end through the plugin boundary: host arrays in, structured rows out (H2D + kernels + D2H)

@@ -326,6 +326,16 @@ int wfa_v1725_index(const uint8_t* buf, int64_t n_bytes, int64_t capacity, int16
 int wfa_width_integral(wfa_ctx* ctx, int source, double q_low, double q_high, double dt,
                        void* out_rows);
 
+/* BasicFeaturesPlugin and WaveformWidthIntegralPlugin records branches (cpu/basic_features.py:108-195,
+ * cpu/waveform_width_integral.py:83-231) on the raw wave_pool in ONE read of the pool: BASELINE config 3 asks for both
+ * tables of the same records.  Uniform records, area range = whole record: one kernel stages every group of records once
+ * and forms both rows (the same additions in the same order as the two separate kernels: identical bytes); any other
+ * layout / range runs the two kernels one after the other.  out_basic (36-byte rows) / out_width (52-byte rows) may be NULL:
+ * the tables then stay on the device only. */
+int wfa_features_both(wfa_ctx* ctx, int64_t height_start, int64_t height_end, int height_has_end, int64_t area_start,
+                      int64_t area_end, int area_has_end, double q_low, double q_high, double dt, void* out_basic,
+                      void* out_width);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* on = 1: every kernel launch is bracketed by HIP events on the ctx stream.  on = 2: only the streaming (mask) kernel

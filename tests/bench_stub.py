@@ -28,6 +28,7 @@ class Session:
 
     def upload_records(self, rec, thr):
         self.n_rec = len(rec)
+        self._chan0 = int(rec["channel"][0]) if len(rec) else 0
 
     def set_sg_plan(self, w, p):
         return None
@@ -54,7 +55,11 @@ class Session:
         return {"k_sg_runs32<baseline>": (1.0, 1)}
 
     def _fill_hits(self, n):
-        return np.zeros(n, dtype=THRESHOLD_HIT_DTYPE)
+        rows = np.zeros(n, dtype=THRESHOLD_HIT_DTYPE)
+        rows["position"] = np.arange(n) + 1000 * self.device_id  # something a checksum can tell apart
+        rows["record_id"] = np.arange(n)[::-1] + 7 * self.device_id
+        rows["channel"] = (np.arange(n) * 2 + getattr(self, "_chan0", 0)) % 32
+        return rows
 
     @staticmethod
     def rccl_unique_id():
@@ -73,7 +78,15 @@ class Session:
         dist.all_gather(t, torch.tensor([n_rows], dtype=torch.int64))
         counts = np.array([int(x.item()) for x in t], dtype=np.int64)
         self._gathered = int(counts.sum())
-        return counts, None
+        if not download:
+            return counts, None
+        mine = self._fill_hits(n_rows)
+        if os.environ.get("WFA_BENCH_STUB_CORRUPT_C4") and self.rank == self.n_ranks - 1 and len(mine):
+            mine["position"][0] += 1                              # what arrives is not what the rank digested
+        payload = [None] * self.n_ranks
+        dist.all_gather_object(payload, mine.tobytes())
+        table = np.concatenate([np.frombuffer(b, dtype=row_dtype) for b in payload]) if self.rank == root else None
+        return counts, table
 
     def hit_rows_source(self, which):
         return None

@@ -18,7 +18,7 @@ def _run(extra_env, port):
     env.pop("RANK", None)
     env.update(extra_env)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--records", "2000", "--steps", "2", "--warmup", "1",
-           "--no-features", "--no-cpu-baseline", "--master-port", str(port)]
+           "--no-features", "--no-cpu-baseline", "--c4-records", "600", "--master-port", str(port)]
     return subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
 
 
@@ -32,6 +32,34 @@ def test_gpus_2_self_launch_prints_one_line_and_exits_zero():
     assert d["config"]["samples_per_gpu"] == 2000 * 800
     assert abs(d["value"] - 2 * 1.6e6 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-3 * d["value"] + 1e-9   # whole-job aggregate
     assert d["gather"]["hits_total"] == 1000 + 1001 and d["gather"]["events"] is not None
+    # the untimed config-4 leg: 256-channel VX2730 records dealt to the ranks, gathered, verified against the ranks' digests
+    c4 = d["gather"]["config4"]
+    assert c4["preset"] == "vx2730" and c4["samples_per_gpu"] == 600 * 1500 and c4["verified"] is True
+    assert c4["hits_total"] == 300 + 301 and c4["gather_ms"] >= 0 and c4["events"] is not None
+
+
+def test_config4_table_that_differs_from_the_digests_fails_the_run():
+    p = _run({"WFA_BENCH_STUB_CORRUPT_C4": "1"}, 29715)
+    assert p.returncode != 0
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["gather_ok"] is False and d["gather"]["config4"]["verified"] is False
+
+
+def test_row_digest_is_order_independent_and_sensitive():
+    import numpy as np
+
+    sys.path.insert(0, REPO)
+    import bench
+    from waveformanalysis_amd.dtypes import THRESHOLD_HIT_DTYPE
+
+    rng = np.random.default_rng(1)
+    rows = np.zeros(1000, dtype=THRESHOLD_HIT_DTYPE)
+    rows["position"], rows["height"], rows["record_id"] = rng.integers(0, 1 << 40, 1000), rng.normal(size=1000), rng.integers(0, 9, 1000)
+    a = bench.row_digest(rows)
+    assert a == bench.row_digest(rows[rng.permutation(1000)]) and a[0] == 1000
+    other = rows.copy()
+    other["record_id"][500] += 1                       # the last field of the row: bytes 52..59 (a zero-extended tail word)
+    assert bench.row_digest(other) != a and bench.row_digest(rows[:0]) == (0, 0)
 
 
 def test_failed_gather_is_reported_and_exits_nonzero():

@@ -115,6 +115,11 @@ def test_full_chunk_features(chunk):
         assert np.all((lo >= 0) & (hi <= 800) & (lo <= hi))
         assert np.all(bf["max_abs_diff"] >= 0) and np.all(np.isfinite(bf["area"]))
 
+        sess.profile(True)                                            # one read of the pool for both tables
+        bf_both, wi_both = sess.features_both((40, 90), (0, None), 0.1, 0.9, 2.0)
+        assert "k_features_both_leaf" in sess.profile_report()
+        assert bf_both.tobytes() == bf.tobytes() and wi_both.tobytes() == wi.tobytes()
+
         sess.set_option("no_span", True)                              # the general kernels
         bf_general = sess.basic_features(_lib.SRC_RAW, (40, 90), (0, None))
         wi_general = sess.width_integral(_lib.SRC_RAW, 0.1, 0.9, 2.0)

@@ -109,6 +109,33 @@ def test_basic_features(sess, name):
 
 
 @pytest.mark.parametrize("name", G.case_names())
+def test_features_both_in_one_read(sess, name):
+    """wfa_features_both: both feature tables of the raw pool from one call, against the reference's two tables.  Uniform
+    records with the plugins' default area range take the fused kernel (one staging of every record group), everything
+    else the two kernels in turn -- bit-exact either way."""
+    case = G.load_case(name)
+    if "bf_raw" not in case or "wi_raw" not in case:
+        pytest.skip("no raw feature tables in this fixture")
+    bp, wp = G.bf_params(case), G.wi_params(case)
+    if not np.all(np.isnan(bp["fixed_baseline"])):
+        pytest.skip("per-channel fixed baselines: the separate basic_features call covers them")
+    dt = wp["dt"] if wp["dt"] is not None else 1.0 / wp["sampling_rate"]
+    sess.upload_pool(case["wave_pool"])
+    sess.upload_records(case["records"])
+    sess.profile(True)
+    bf, wi = sess.features_both(bp["height_range"], bp["area_range"], wp["q_low"], wp["q_high"], float(dt))
+    names = sess.profile_report()
+    rec = case["records"]
+    uniform = len(rec) > 0 and np.all(rec["event_length"] == rec["event_length"][0]) and \
+        np.array_equal(rec["wave_offset"], rec["wave_offset"][0] + np.arange(len(rec)) * int(rec["event_length"][0]))
+    if uniform and tuple(bp["area_range"]) == (0, None) and rec["event_length"][0] % 8 == 0 and rec["wave_offset"][0] % 8 == 0 \
+            and rec["event_length"][0] >= 24:                          # (span mode of the upload: wfa_capi.hip)
+        assert "k_features_both_leaf" in names, sorted(names)
+    G.assert_struct_equal(bf, case["bf_raw"], what=f"{name} fused basic features (bit-exact)")
+    G.assert_struct_equal(wi, case["wi_raw"], what=f"{name} fused width integral (bit-exact)")
+
+
+@pytest.mark.parametrize("name", G.case_names())
 def test_width_integral(sess, name):
     case = G.load_case(name)
     wp = G.wi_params(case)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "wfa_pool_gather": (_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i64]),
     "wfa_basic_features": (_int, [_p, _int, _i64, _i64, _int, _i64, _i64, _int, _p, _p]),
     "wfa_width_integral": (_int, [_p, _int, _f64, _f64, _f64, _p]),
+    "wfa_features_both": (_int, [_p, _i64, _i64, _int, _i64, _i64, _int, _f64, _f64, _f64, _p, _p]),
     "wfa_profile_enable": (_int, [_p, _int]),
     "wfa_profile_reset": (_int, [_p]),
     "wfa_profile_get": (_int, [_p, _int, C.c_char_p, C.c_size_t, C.POINTER(_f64), C.POINTER(_i64)]),

@@ -733,7 +733,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                       &c->hit_desc, &c->bw_scratch, &c->peak_out, &c->peak_cand_n, &c->peak_cand_pos, &c->peak_cand_val, &c->peak_slot_pos, &c->peak_slot_val,
                         &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
-                      &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows,
+                      &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows, &c->out_rows2,
                       &c->gathered, &c->pw_plan, &c->fw_ties, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
                       &c->shadow_pool, &c->shadow_off};
     for (DevBuf* b : bufs) b->release();
@@ -1527,6 +1527,52 @@ int wfa_width_integral(wfa_ctx* c, int source, double q_low, double q_high, doub
         }
     }
     WFA_HIP_CHECK(hipMemcpyAsync(out_rows, c->out_rows.ptr, (size_t)c->R * 52, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_features_both(wfa_ctx* c, int64_t h0, int64_t h1, int h_has_end, int64_t a0, int64_t a1, int a_has_end,
+                      double q_low, double q_high, double dt, void* out_basic, void* out_width) {
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = need_source(c, WFA_SRC_RAW))) return rc;
+    if (!(q_low > 0.0) || !(q_high < 1.0) || !(q_low < q_high))  // waveform_width_integral.py:95-96
+        return fail(WFA_E_INVALID, "q_low/q_high invalid: q_low=%g, q_high=%g", q_low, q_high);
+    if (c->R == 0) return WFA_OK;
+    FeatParams fp{};
+    fp.h0 = h0; fp.h1 = h1; fp.h_has_end = h_has_end;
+    fp.a0 = a0; fp.a1 = a1; fp.a_has_end = a_has_end;
+    fp.fixed_bl = nullptr;
+    WidthParams wp{q_low, q_high, dt};
+    if ((rc = c->out_rows.ensure((size_t)c->R * 36)) || (rc = c->out_rows2.ensure((size_t)c->R * 52))) return rc;
+    uint8_t* ob = c->out_rows.as<uint8_t>();
+    uint8_t* ow = c->out_rows2.as<uint8_t>();
+    {
+        LaunchTimer t(c);
+        hipError_t e = hipSuccess;
+        if (launch_features_both_wave(c, rec_view(c), fp, wp, ob, ow, &e)) {
+            WFA_HIP_CHECK(e);
+            if ((rc = t.end("k_features_both_leaf"))) return rc;
+        } else {  // layout or ranges outside the fused kernel: the two kernels, one after the other
+            if (launch_basic_features_wave(c, rec_view(c), fp, ob, &e)) {
+                WFA_HIP_CHECK(e);
+                if ((rc = t.end("k_basic_features_leaf"))) return rc;
+            } else {
+                WFA_HIP_CHECK(launch_basic_features(c->stream, WFA_SRC_RAW, pool_view(c), rec_view(c), sg_params(c), fp, ob));
+                if ((rc = t.end("k_basic_features"))) return rc;
+            }
+            LaunchTimer t2(c);
+            if (launch_width_integral_wave(c, rec_view(c), wp, ow, &e)) {
+                WFA_HIP_CHECK(e);
+                if ((rc = t2.end("k_width_integral_leaf"))) return rc;
+            } else {
+                WFA_HIP_CHECK(launch_width_integral(c->stream, WFA_SRC_RAW, pool_view(c), rec_view(c), sg_params(c), wp, ow));
+                if ((rc = t2.end("k_width_integral"))) return rc;
+            }
+        }
+    }
+    if (out_basic) WFA_HIP_CHECK(hipMemcpyAsync(out_basic, ob, (size_t)c->R * 36, hipMemcpyDeviceToHost, c->stream));
+    if (out_width) WFA_HIP_CHECK(hipMemcpyAsync(out_width, ow, (size_t)c->R * 52, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return WFA_OK;
 }

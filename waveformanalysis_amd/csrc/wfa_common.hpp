@@ -131,6 +131,7 @@ struct wfa_ctx {
     int64_t last_hits = -1;  // hits of the previous fast-path pass on this context (sizes the speculative tail)
 
     wfa::DevBuf out_rows;  // per-record feature rows
+    wfa::DevBuf out_rows2; // the second table of wfa_features_both (width rows)
     wfa::DevBuf pw_plan;   // numpy pairwise-sum plan of the wave-per-record feature kernels (wfa_features.hip)
     int pw_plan_n = -1;    // reduction length the device copy was built for
     wfa::DevBuf fw_ties;   // width-integral records whose quantile positions are re-walked in numpy's order

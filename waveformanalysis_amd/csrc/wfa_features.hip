@@ -149,8 +149,10 @@ __device__ __forceinline__ double leaf_sum_lane(const fw_u4* q, int len, int cmi
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = m == 0 ? t[j] : r[j] + t[j];  // r[j] = a[j]; r[j] += a[i + j]
         if (CUM) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tot += t[j];
+            // the running sum only LOCATES the crossing (leaf_crossings accepts an index when nothing lies within
+            // 8 L 2^-53 of the target, numpy's own order decides the rest): a chunk enters it as one value, three
+            // dependent additions deep instead of eight
+            tot += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         }
     };
     constexpr int B = 4;  // chunks read together (registers: the basic-features kernel runs at 3 waves per SIMD)
@@ -180,6 +182,58 @@ __device__ __forceinline__ double leaf_sum_lane(const fw_u4* q, int len, int cmi
             if (j < nt) { res += t[j]; if (CUM) tot += t[j]; }
     }
     if (CUM) cs[kFwMaxChunks] = tot;
+    return res;
+}
+
+// Both reductions of a record from ONE walk of the leaf (MODE 2): the unclipped terms into rb (basic_features' area), the
+// same terms clipped at zero into the width kernel's accumulators and running sums.  Same additions, same operands, same
+// order as the two separate walks -- the chunk is read and converted once.
+template <class F>
+__device__ __forceinline__ double leaf_sum_lane_both(const fw_u4* q, int len, int cmin, int cmax, const F& f,
+                                                     double (&cs)[kFwMaxChunks + 1], double& res_plain) {
+    const int cnt = len >> 3, nt = len & 7;
+    double r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tot = 0.0;
+    auto take = [&](int m, const fw_u4& v) __attribute__((always_inline)) {
+        double t[8];
+        chunk_terms<false>(v, f, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = m == 0 ? t[j] : rb[j] + t[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = __builtin_fmax(t[j], 0.0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = m == 0 ? t[j] : r[j] + t[j];
+        tot += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));  // (see leaf_sum_lane)
+    };
+    constexpr int B = 2;  // (two accumulator sets live here: four chunks in flight spilled)
+#pragma unroll
+    for (int mb = 0; mb < kFwMaxChunks; mb += B) {
+        if (mb + B <= cmin) {
+            fw_u4 v[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) v[i] = q[mb + i];
+#pragma unroll
+            for (int i = 0; i < B; ++i) { take(mb + i, v[i]); cs[mb + i] = tot; }
+        } else {
+#pragma unroll
+            for (int m = mb; m < mb + B; ++m) {
+                if (m < cmax && m < cnt) take(m, q[m]);
+                cs[m] = tot;
+            }
+        }
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    double resb = ((rb[0] + rb[1]) + (rb[2] + rb[3])) + ((rb[4] + rb[5]) + (rb[6] + rb[7]));
+    if (cnt == 0) { res = 0.0; resb = 0.0; }
+    if (nt) {
+        double t[8];
+        chunk_terms<false>(q[cnt], f, t);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (j < nt) { resb += t[j]; const double tc = __builtin_fmax(t[j], 0.0); res += tc; tot += tc; }
+    }
+    cs[kFwMaxChunks] = tot;
+    res_plain = resb;
     return res;
 }
 
@@ -278,12 +332,15 @@ struct FwCold {  // columns that are only copied into the row: loaded at the end
     uint32_t board, chan;
 };
 
-// MODE 0: BASIC_FEATURES_DTYPE rows (36 B); MODE 1: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B).
+// MODE 0: BASIC_FEATURES_DTYPE rows (36 B); MODE 1: WAVEFORM_WIDTH_INTEGRAL_DTYPE rows (52 B); MODE 2: both from one
+// staging of the group (BASELINE config 3 reads the pool once for the two feature tables: area range = whole record, no
+// fixed baselines -- the plugins' defaults; `out` = the basic rows, `out2` = the width rows).
 // A wave takes a group of 64 >> gl_shift consecutive records; lane = (record of the group, leaf of the reduction).
 // PFN: 16-byte chunks a lane stages per group (13 covers 8 records of up to 832 samples).
 template <int MODE, int PFN>
 __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
-                                                            uint8_t* __restrict__ out) {
+                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ out2) {
+    constexpr bool DO_B = MODE != 1, DO_W = MODE != 0;
     __shared__ PwPlan plan;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     {
@@ -322,24 +379,34 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
         }
         const int64_t r = g < nrec ? r0 + g : r0;  // a lane past the end repeats the group's first record (never written)
         nx.bl = rec.baseline[r];
-        nx.fb = (MODE == 0 && fw.fixed_bl) ? fw.fixed_bl[r] : 0.0;
+        nx.fb = (MODE == 0 && fw.fixed_bl) ? fw.fixed_bl[r] : 0.0;  // (MODE 2 is not launched with fixed baselines)
         nx.pol = rec.pol[r];
     };
 
     // A row is stored one group late, in front of the next prefetch: vmcnt counts loads and stores in order, so a store
     // issued after the prefetch would make the wait for the prefetched samples wait for the store's round trip too.
-    constexpr int kRowDw = MODE == 0 ? 9 : 13, kRowKeep = MODE == 0 ? 4 : 8;  // dwords computed here: 4 floats / 6 floats + q
-    uint32_t prow[kRowKeep];
+    // dwords computed here: 4 floats (basic) / 6 floats + q (width); the id columns follow in both layouts
+    uint32_t prow_b[DO_B ? 4 : 1], prow_w[DO_W ? 8 : 1];
     FwCold cold;
     auto flush_row = [&](int64_t done) __attribute__((always_inline)) {  // the rows of group `done`, formed one turn ago
         const int64_t r = done * RW + g;
         if (k == 0 && r < rec.R) {
-            uint32_t* at = reinterpret_cast<uint32_t*>(out + r * (kRowDw * 4));
+            if (DO_B) {
+                uint32_t* at = reinterpret_cast<uint32_t*>(out + r * 36);
 #pragma unroll
-            for (int i = 0; i < kRowKeep; ++i) at[i] = prow[i];
-            put_i64(at, kRowKeep, cold.ts);
-            at[kRowKeep + 2] = cold.board | (cold.chan << 16);
-            put_i64(at, kRowKeep + 3, r);
+                for (int i = 0; i < 4; ++i) at[i] = prow_b[i];
+                put_i64(at, 4, cold.ts);
+                at[6] = cold.board | (cold.chan << 16);
+                put_i64(at, 7, r);
+            }
+            if (DO_W) {
+                uint32_t* at = reinterpret_cast<uint32_t*>((MODE == 2 ? out2 : out) + r * 52);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) at[i] = prow_w[i];
+                put_i64(at, 8, cold.ts);
+                at[10] = cold.board | (cold.chan << 16);
+                put_i64(at, 11, r);
+            }
         }
     };
     auto fetch_cold = [&](int64_t r) __attribute__((always_inline)) {
@@ -393,9 +460,13 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
         const fw_u4* q = reinterpret_cast<const fw_u4*>(mine + fw.c0 + la);  // c0 % 8 == 0, la % 8 == 0
         const int cmin = plan.min_len >> 3, cmax = (plan.max_len + 7) >> 3;
         double cs[kFwMaxChunks + 1];
-        double res;
-        constexpr bool W = MODE == 1;
-        if (all_known) res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, tk, cs);
+        double res, res_b = 0.0;  // res: the reduction of MODE 0 / 1, in MODE 2 the clipped one (res_b the plain one)
+        constexpr bool W = MODE != 0;
+        if (MODE == 2) {
+            if (all_known) res = leaf_sum_lane_both(q, llen, cmin, cmax, tk, cs, res_b);
+            else if (all_wave) res = leaf_sum_lane_both(q, llen, cmin, cmax, tw, cs, res_b);
+            else res = leaf_sum_lane_both(q, llen, cmin, cmax, TermMixed{tk, tw, known}, cs, res_b);
+        } else if (all_known) res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, tk, cs);
         else if (all_wave) res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, tw, cs);
         else res = leaf_sum_lane<W, W>(q, llen, cmin, cmax, TermMixed{tk, tw, known}, cs);
         if (W && !leaf_live) {
@@ -405,32 +476,102 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
         FW_T(2);  // leaf sums
         // the leaves of a record combine along numpy's recursion tree
         double* ls = leaf_sum + g * GL;
-        double root;
-        if (plan.dpp_tree) {  // balanced: level l pairs the lanes 2^l apart (a + b == b + a bit for bit)
-            root = res;
-            if (plan.n_level > 0) root += fw_dpp_f64(root, 0);
-            if (plan.n_level > 1) root += fw_dpp_f64(root, 1);
-            if (plan.n_level > 2) root += fw_dpp_f64(root, 2);
-            if (plan.n_level > 3) root += fw_dpp_f64(root, 3);
-            if (GL != plan.n_leaf) root = __shfl(root, 0, GL);  // lanes without a leaf need it too
-        } else {
-            if (leaf_live) ls[k] = res;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            for (int lv = 0; lv < plan.n_level; ++lv) {
-                const int p = leaf_live ? plan.partner[lv][k] : -1;
-                double v = 0.0;
-                if (p >= 0) v = ls[k] + ls[p];
+        auto combine = [&](double leaf_value) __attribute__((always_inline)) {
+            double root;
+            if (plan.dpp_tree) {  // balanced: level l pairs the lanes 2^l apart (a + b == b + a bit for bit)
+                root = leaf_value;
+                if (plan.n_level > 0) root += fw_dpp_f64(root, 0);
+                if (plan.n_level > 1) root += fw_dpp_f64(root, 1);
+                if (plan.n_level > 2) root += fw_dpp_f64(root, 2);
+                if (plan.n_level > 3) root += fw_dpp_f64(root, 3);
+                if (GL != plan.n_leaf) root = __shfl(root, 0, GL);  // lanes without a leaf need it too
+            } else {
+                if (leaf_live) ls[k] = leaf_value;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (p >= 0) ls[k] = v;
+                for (int lv = 0; lv < plan.n_level; ++lv) {
+                    const int p = leaf_live ? plan.partner[lv][k] : -1;
+                    double v = 0.0;
+                    if (p >= 0) v = ls[k] + ls[p];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (p >= 0) ls[k] = v;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                root = plan.n_leaf > 0 ? ls[0] : 0.0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            root = plan.n_leaf > 0 ? ls[0] : 0.0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        const double total = 0.0 + (plan.n_leaf > 0 ? root : 0.0);
+            return 0.0 + (plan.n_leaf > 0 ? root : 0.0);
+        };
+        const double total = combine(res);                              // MODE 0: plain sum; MODE 1 / 2: clipped sum
+        const double total_plain = MODE == 2 ? combine(res_b) : total;  // basic_features' area
         FW_T(3);  // tree
 
-        if (MODE == 0) {
+        // (the width part first: the per-chunk running sums die there, before the extremes of the basic part need registers)
+        if (DO_W) {
+            // quantile positions of x_i = max(signal_i, 0) (waveform_width_integral.py:180-231).  np.cumsum is sequential:
+            // here each lane has the sequential sums of its own leaf and a scan over the record's lanes places them; a
+            // decision closer than `tol` to a target is re-made by one lane in numpy's order.
+            const double qsum = total;
+            const bool ok = qsum > 0.0 && qsum <= 1.7976931348623157e308;  // finite and positive
+            const double t_lo = fw.q_low * qsum, t_hi = fw.q_high * qsum;
+            double incl = cs[kFwMaxChunks];
+            double excl;
+            if (GL <= 16) {  // a record's lanes sit in one row of 16: DPP shifts, no LDS round trips
+                double o;
+                if (GL > 1) { o = fw_row_shr_f64<1>(incl); if (k >= 1) incl += o; }
+                if (GL > 2) { o = fw_row_shr_f64<2>(incl); if (k >= 2) incl += o; }
+                if (GL > 4) { o = fw_row_shr_f64<4>(incl); if (k >= 4) incl += o; }
+                if (GL > 8) { o = fw_row_shr_f64<8>(incl); if (k >= 8) incl += o; }
+                excl = fw_row_shr_f64<1>(incl);
+            } else {
+                for (int d = 1; d < GL; d <<= 1) {
+                    const double o = __shfl_up(incl, d, GL);
+                    if (k >= d) incl += o;
+                }
+                excl = __shfl_up(incl, 1, GL);
+            }
+            if (k == 0) excl = 0.0;
+            FW_T(5);  // scan
+            const double eps = 8.0 * (double)L * 1.1102230246251565e-16;
+            const double tt[2] = {t_lo, t_hi}, tol[2] = {eps * t_lo, eps * t_hi};
+            int fnd[2];
+            bool nr[2];
+            if (all_known) leaf_crossings(q, la, llen, tk, cs, excl, tt, tol, fnd, nr);
+            else if (all_wave) leaf_crossings(q, la, llen, tw, cs, excl, tt, tol, fnd, nr);
+            else leaf_crossings(q, la, llen, TermMixed{tk, tw, known}, cs, excl, tt, tol, fnd, nr);
+            FW_T(6);  // crossings
+            if (!leaf_live) { fnd[0] = INT32_MAX; fnd[1] = INT32_MAX; nr[0] = false; nr[1] = false; }
+            const int f_lo = fnd[0], f_hi = fnd[1];
+            const int g_lo = group_min_i32(f_lo, GL), g_hi = group_min_i32(f_hi, GL);
+            // lanes at or in front of the record's first crossing saw values around the target; the ones behind it did not
+            bool amb = (nr[0] && (f_lo == g_lo || f_lo == INT32_MAX)) || (nr[1] && (f_hi == g_hi || f_hi == INT32_MAX));
+            if (__ballot(g_lo == INT32_MAX || g_hi == INT32_MAX)) {  // no crossing at all: the last cumulative value decides
+                const double last = __shfl(incl, GL - 1, GL);
+                amb = amb || (g_lo == INT32_MAX && t_lo - last <= eps * t_lo) || (g_hi == INT32_MAX && t_hi - last <= eps * t_hi);
+            }
+            int amb_i = amb ? 1 : 0;
+            amb_i = group_max_i32(amb_i, GL);
+            int lo_i = g_lo == INT32_MAX ? L : g_lo;  // np.searchsorted returns len(cumsum)
+            int hi_i = g_hi == INT32_MAX ? L : g_hi;
+            FW_T(7);  // reductions
+            if (amb_i && ok && valid && k == 0) {  // numpy's own order decides: k_width_ties re-walks the record
+                const int slot = atomicAdd(fw.ties, 1);
+                fw.ties[1 + slot] = (int32_t)r;
+            }
+            if (!ok) { lo_i = 0; hi_i = 0; }
+            if (valid && k == 0) {
+                uint32_t* row = prow_w;
+                const double lo = (double)lo_i, hi = (double)hi_i;
+                const double w = (double)(hi_i - lo_i > 0 ? hi_i - lo_i : 0);
+                put_f32(row, 0, (float)(lo * fw.dt));
+                put_f32(row, 1, (float)(hi * fw.dt));
+                put_f32(row, 2, (float)(w * fw.dt));
+                put_f32(row, 3, (float)lo);
+                put_f32(row, 4, (float)hi);
+                put_f32(row, 5, (float)w);
+                put_f64(row, 6, qsum);
+            }
+        }
+        if (DO_B) {
             // min / max of the raw samples over the height range: the record's lanes stride over it, four reads in flight
             int wmin = INT32_MAX, wmax = INT32_MIN;
             {
@@ -490,7 +631,7 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
             wmax = group_max_i32(wmax, GL);
             dmax = group_max_i32(dmax, GL);
             if (valid && k == 0) {
-                uint32_t* row = prow;
+                uint32_t* row = prow_b;
                 float height = 0.f, amp = 0.f, area_f = 0.f, mad_f = 0.f;
                 if (fw.p1 > fw.p0) {
                     double vmin, vmax;  // of `val` as the reference forms it (monotone in the sample)
@@ -505,76 +646,12 @@ __global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecV
                     height = known ? (float)vmax : (wpos ? (float)(vmax - baseline) : (float)(baseline - vmin));
                     amp = (float)(vmax - vmin);
                 }
-                if (fw.c1 > fw.c0) area_f = (float)total;
+                if (fw.c1 > fw.c0) area_f = (float)total_plain;
                 if (L > 1) mad_f = (float)(double)dmax;
                 put_f32(row, 0, height);
                 put_f32(row, 1, amp);
                 put_f32(row, 2, area_f);
                 put_f32(row, 3, mad_f);
-            }
-        } else {
-            // quantile positions of x_i = max(signal_i, 0) (waveform_width_integral.py:180-231).  np.cumsum is sequential:
-            // here each lane has the sequential sums of its own leaf and a scan over the record's lanes places them; a
-            // decision closer than `tol` to a target is re-made by one lane in numpy's order.
-            const double qsum = total;
-            const bool ok = qsum > 0.0 && qsum <= 1.7976931348623157e308;  // finite and positive
-            const double t_lo = fw.q_low * qsum, t_hi = fw.q_high * qsum;
-            double incl = cs[kFwMaxChunks];
-            double excl;
-            if (GL <= 16) {  // a record's lanes sit in one row of 16: DPP shifts, no LDS round trips
-                double o;
-                if (GL > 1) { o = fw_row_shr_f64<1>(incl); if (k >= 1) incl += o; }
-                if (GL > 2) { o = fw_row_shr_f64<2>(incl); if (k >= 2) incl += o; }
-                if (GL > 4) { o = fw_row_shr_f64<4>(incl); if (k >= 4) incl += o; }
-                if (GL > 8) { o = fw_row_shr_f64<8>(incl); if (k >= 8) incl += o; }
-                excl = fw_row_shr_f64<1>(incl);
-            } else {
-                for (int d = 1; d < GL; d <<= 1) {
-                    const double o = __shfl_up(incl, d, GL);
-                    if (k >= d) incl += o;
-                }
-                excl = __shfl_up(incl, 1, GL);
-            }
-            if (k == 0) excl = 0.0;
-            FW_T(5);  // scan
-            const double eps = 8.0 * (double)L * 1.1102230246251565e-16;
-            const double tt[2] = {t_lo, t_hi}, tol[2] = {eps * t_lo, eps * t_hi};
-            int fnd[2];
-            bool nr[2];
-            if (all_known) leaf_crossings(q, la, llen, tk, cs, excl, tt, tol, fnd, nr);
-            else if (all_wave) leaf_crossings(q, la, llen, tw, cs, excl, tt, tol, fnd, nr);
-            else leaf_crossings(q, la, llen, TermMixed{tk, tw, known}, cs, excl, tt, tol, fnd, nr);
-            FW_T(6);  // crossings
-            if (!leaf_live) { fnd[0] = INT32_MAX; fnd[1] = INT32_MAX; nr[0] = false; nr[1] = false; }
-            const int f_lo = fnd[0], f_hi = fnd[1];
-            const int g_lo = group_min_i32(f_lo, GL), g_hi = group_min_i32(f_hi, GL);
-            // lanes at or in front of the record's first crossing saw values around the target; the ones behind it did not
-            bool amb = (nr[0] && (f_lo == g_lo || f_lo == INT32_MAX)) || (nr[1] && (f_hi == g_hi || f_hi == INT32_MAX));
-            if (__ballot(g_lo == INT32_MAX || g_hi == INT32_MAX)) {  // no crossing at all: the last cumulative value decides
-                const double last = __shfl(incl, GL - 1, GL);
-                amb = amb || (g_lo == INT32_MAX && t_lo - last <= eps * t_lo) || (g_hi == INT32_MAX && t_hi - last <= eps * t_hi);
-            }
-            int amb_i = amb ? 1 : 0;
-            amb_i = group_max_i32(amb_i, GL);
-            int lo_i = g_lo == INT32_MAX ? L : g_lo;  // np.searchsorted returns len(cumsum)
-            int hi_i = g_hi == INT32_MAX ? L : g_hi;
-            FW_T(7);  // reductions
-            if (amb_i && ok && valid && k == 0) {  // numpy's own order decides: k_width_ties re-walks the record
-                const int slot = atomicAdd(fw.ties, 1);
-                fw.ties[1 + slot] = (int32_t)r;
-            }
-            if (!ok) { lo_i = 0; hi_i = 0; }
-            if (valid && k == 0) {
-                uint32_t* row = prow;
-                const double lo = (double)lo_i, hi = (double)hi_i;
-                const double w = (double)(hi_i - lo_i > 0 ? hi_i - lo_i : 0);
-                put_f32(row, 0, (float)(lo * fw.dt));
-                put_f32(row, 1, (float)(hi * fw.dt));
-                put_f32(row, 2, (float)(w * fw.dt));
-                put_f32(row, 3, (float)lo);
-                put_f32(row, 4, (float)hi);
-                put_f32(row, 5, (float)w);
-                put_f64(row, 6, qsum);
             }
         }
         fetch_cold(r);  // behind the prefetch in the queue, which the next turn waits for anyway
@@ -641,7 +718,8 @@ __global__ __launch_bounds__(64) void k_width_ties(FwParams fw, RecView rec, uin
 
 // Uniform records (wfa_ctx::span_ok), uint16 pool, reduction length <= 8192: the lane-per-leaf kernels.  Returns
 // false when the layout is outside that (the caller launches the general lane-per-record kernel).
-static bool features_wave(wfa_ctx* c, int mode, const RecView& rec, FwParams fw, int n_sum, uint8_t* out, hipError_t* err) {
+static bool features_wave(wfa_ctx* c, int mode, const RecView& rec, FwParams fw, int n_sum, uint8_t* out, hipError_t* err,
+                          uint8_t* out2 = nullptr) {
     *err = hipSuccess;
     if (!c->span_ok || c->span_L < 8 || c->span_L > kFwGroupSamples || c->opt.no_span) return false;
     if (fw.c0 % 8) return false;  // leaves start on 16-byte chunks of the staged record
@@ -657,7 +735,7 @@ static bool features_wave(wfa_ctx* c, int mode, const RecView& rec, FwParams fw,
     fw.pool = c->pool_u16.as<uint16_t>();
     fw.off0 = c->span_off0;
     fw.L = c->span_L;
-    if (mode == 1) {
+    if (mode >= 1) {
         if (rec.R >= INT32_MAX || c->fw_ties.ensure(((size_t)rec.R + 1) * sizeof(int32_t)) != WFA_OK) return false;
         fw.ties = c->fw_ties.as<int32_t>();
         *err = hipMemsetAsync(fw.ties, 0, sizeof(int32_t), c->stream);
@@ -672,19 +750,24 @@ static bool features_wave(wfa_ctx* c, int mode, const RecView& rec, FwParams fw,
     const int64_t n_groups = (rec.R + RW - 1) / RW;
     // persistent waves (each prefetches its next group): exactly the blocks that are resident together
     const bool small = (int64_t)RW * (fw.L >> 3) <= 13 * kWave;
-    const void* fn = mode == 0 ? (small ? reinterpret_cast<const void*>(k_features_leaf<0, 13>) : reinterpret_cast<const void*>(k_features_leaf<0, 16>))
-                               : (small ? reinterpret_cast<const void*>(k_features_leaf<1, 13>) : reinterpret_cast<const void*>(k_features_leaf<1, 16>));
+    const void* fns[3][2] = {
+        {reinterpret_cast<const void*>(k_features_leaf<0, 16>), reinterpret_cast<const void*>(k_features_leaf<0, 13>)},
+        {reinterpret_cast<const void*>(k_features_leaf<1, 16>), reinterpret_cast<const void*>(k_features_leaf<1, 13>)},
+        {reinterpret_cast<const void*>(k_features_leaf<2, 16>), reinterpret_cast<const void*>(k_features_leaf<2, 13>)}};
+    const void* fn = fns[mode][small ? 1 : 0];
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFwBlock, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     int64_t g = (n_groups + kFwWaves - 1) / kFwWaves;
     if (g > (int64_t)kFwCUs * per_cu) g = (int64_t)kFwCUs * per_cu;
     const PwPlan* dplan = c->pw_plan.as<PwPlan>();
     const dim3 grid((unsigned)g), block(kFwBlock);
-    if (mode == 0 && small) hipLaunchKernelGGL((k_features_leaf<0, 13>), grid, block, lds, c->stream, fw, rec, dplan, out);
-    else if (mode == 0) hipLaunchKernelGGL((k_features_leaf<0, 16>), grid, block, lds, c->stream, fw, rec, dplan, out);
-    else if (small) hipLaunchKernelGGL((k_features_leaf<1, 13>), grid, block, lds, c->stream, fw, rec, dplan, out);
-    else hipLaunchKernelGGL((k_features_leaf<1, 16>), grid, block, lds, c->stream, fw, rec, dplan, out);
-    if (mode == 1 && hipGetLastError() == hipSuccess) hipLaunchKernelGGL(k_width_ties, dim3(256), dim3(64), 0, c->stream, fw, rec, out);
+#define WFA_FW_LAUNCH(M, P) hipLaunchKernelGGL((k_features_leaf<M, P>), grid, block, lds, c->stream, fw, rec, dplan, out, out2)
+    if (mode == 0) { if (small) WFA_FW_LAUNCH(0, 13); else WFA_FW_LAUNCH(0, 16); }
+    else if (mode == 1) { if (small) WFA_FW_LAUNCH(1, 13); else WFA_FW_LAUNCH(1, 16); }
+    else { if (small) WFA_FW_LAUNCH(2, 13); else WFA_FW_LAUNCH(2, 16); }
+#undef WFA_FW_LAUNCH
+    if (mode >= 1 && hipGetLastError() == hipSuccess)
+        hipLaunchKernelGGL(k_width_ties, dim3(256), dim3(64), 0, c->stream, fw, rec, mode == 2 ? out2 : out);
     *err = hipGetLastError();
     return true;
 }
@@ -704,6 +787,18 @@ bool launch_basic_features_wave(wfa_ctx* c, const RecView& rec, const FeatParams
     resolve_slice(fp.a0, fp.a1, fp.a_has_end, c->span_L, fw.c0, fw.c1);
     fw.fixed_bl = fp.fixed_bl;
     return features_wave(c, 0, rec, fw, fw.c1 - fw.c0, out, err);
+}
+
+// both tables from one read of the pool (MODE 2): only for the plugins' default reductions -- the area over the whole
+// record and no per-channel fixed baselines -- where the two kernels walk the same leaves with the same baseline
+bool launch_features_both_wave(wfa_ctx* c, const RecView& rec, const FeatParams& fp, const WidthParams& wp, uint8_t* out_basic,
+                               uint8_t* out_width, hipError_t* err) {
+    FwParams fw{};
+    resolve_slice(fp.h0, fp.h1, fp.h_has_end, c->span_L, fw.p0, fw.p1);
+    resolve_slice(fp.a0, fp.a1, fp.a_has_end, c->span_L, fw.c0, fw.c1);
+    if (fp.fixed_bl || fw.c0 != 0 || fw.c1 != c->span_L) { *err = hipSuccess; return false; }
+    fw.q_low = wp.q_low; fw.q_high = wp.q_high; fw.dt = wp.dt;
+    return features_wave(c, 2, rec, fw, c->span_L, out_basic, err, out_width);
 }
 
 bool launch_width_integral_wave(wfa_ctx* c, const RecView& rec, const WidthParams& wp, uint8_t* out, hipError_t* err) {

@@ -236,6 +236,8 @@ namespace wfa {
 // uniform records: wave-per-record kernels (wfa_features.hip); false = layout not covered, launch the general kernel
 bool launch_basic_features_wave(wfa_ctx* c, const RecView& rec, const FeatParams& fp, uint8_t* out, hipError_t* err);
 bool launch_width_integral_wave(wfa_ctx* c, const RecView& rec, const WidthParams& wp, uint8_t* out, hipError_t* err);
+bool launch_features_both_wave(wfa_ctx* c, const RecView& rec, const FeatParams& fp, const WidthParams& wp, uint8_t* out_basic,
+                               uint8_t* out_width, hipError_t* err);
 hipError_t launch_basic_features(hipStream_t st, int source, const PoolView& pool, const RecView& rec,
                                  const SgParams& sg, const FeatParams& fp, uint8_t* out);
 hipError_t launch_width_integral(hipStream_t st, int source, const PoolView& pool, const RecView& rec,

@@ -535,6 +535,19 @@ class DeviceSession:
                                                 float(dt), _ptr(out)))
         return out
 
+    def features_both(self, height_range=(40, 90), area_range=(0, None), q_low: float = 0.1, q_high: float = 0.9,
+                      dt: float = 2.0, download: bool = True):
+        """basic_features and width_integral rows of the raw pool from one read of it (wfa_features_both) ->
+        (BASIC_FEATURES_DTYPE rows, WAVEFORM_WIDTH_INTEGRAL_DTYPE rows), or (None, None) with download=False."""
+        h0, h1 = height_range
+        a0, a1 = area_range
+        ob = np.zeros(self.n_records, dtype=BASIC_FEATURES_DTYPE) if download else None
+        ow = np.zeros(self.n_records, dtype=WAVEFORM_WIDTH_INTEGRAL_DTYPE) if download else None
+        _lib.check(self._lib.wfa_features_both(
+            self._h, int(h0 or 0), int(h1 or 0), int(h1 is not None), int(a0 or 0), int(a1 or 0), int(a1 is not None),
+            float(q_low), float(q_high), float(dt), _ptr(ob), _ptr(ow)))
+        return ob, ow
+
     def sync(self) -> None:
         _lib.check(self._lib.wfa_sync(self._h))
 
