@@ -51,6 +51,36 @@ def test_audit_flags_a_copy_of_in_flight_registers(tmp_path):
     assert A.main(str(path)) == 0
 
 
+def test_audit_follows_branches(tmp_path):
+    """The data-flow form: a register is in flight on ONE of two paths into a block that reads it."""
+    import audit_asm_loads as A
+
+    asm = """_ZN3wfa11k_sg_runs32ILi11ELi40EEEvNS_8RunsArgsE:
+	s_cbranch_scc1 .LBB0_2
+	;;#ASMSTART
+	s_nop 4
+	buffer_load_dwordx4 v[128:131], v40, s[4:7], s8 offen
+	;;#ASMEND
+	s_branch .LBB0_3
+.LBB0_2:
+	;;#ASMSTART
+	buffer_load_dwordx4 v[128:131], v40, s[4:7], s8 offen
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(5) ; v[128:131]
+	;;#ASMEND
+.LBB0_3:
+	v_xor_b32_e32 v1, v2, v129
+	s_endpgm
+.Lfunc_end0:
+"""
+    path = tmp_path / "k.s"
+    path.write_text(asm)
+    assert A.main(str(path)) == 1                      # the fall-through path never waited
+    path.write_text(asm.replace("	s_branch .LBB0_3\n", "	;;#ASMSTART\n	s_waitcnt vmcnt(0) ; v[128:131]\n	;;#ASMEND\n	s_branch .LBB0_3\n"))
+    assert A.main(str(path)) == 0
+
+
 def test_traffic_entries_go_stale_with_the_kernel_sources(tmp_path, monkeypatch):
     sys.path.insert(0, REPO)
     import json

@@ -59,6 +59,82 @@ def dot_hazards(name: str, lines: list) -> int:
     return bad
 
 
+def flow_audit(name: str, lines: list) -> int:
+    """Control-flow-aware form of the in-flight rule, for kernels whose tile buffers are fixed registers named in the
+    assembly text (issue statements without outputs): a forward data-flow over the basic blocks -- a buffer register is
+    'in flight' from a `buffer_load` inside an ASM block that writes it until an ASM `s_waitcnt vmcnt` statement whose
+    comment names it; an instruction that touches a register which may be in flight on SOME path is an error."""
+    # ---- instructions and blocks
+    insts = []  # (line number, text, in_asm)
+    labels = {}
+    in_asm = False
+    for k, raw in enumerate(lines):
+        ln = raw.strip()
+        if ";;#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in ln:
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            labels[m.group(1)] = len(insts)
+            continue
+        code = ln if in_asm else ln.split(";")[0].strip()
+        if not code or code.startswith(".") or code.startswith(";") or code.endswith(":"):
+            continue
+        insts.append((k, code, in_asm))
+    n = len(insts)
+    if n == 0:
+        return 0
+
+    def succ(i):
+        op = insts[i][1].split()[0]
+        out = []
+        if op in ("s_endpgm", "s_setpc_b64"):
+            return out
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            tgt = insts[i][1].split()[-1]
+            if tgt in labels and labels[tgt] < n:
+                out.append(labels[tgt])
+            if op == "s_branch":
+                return out
+        if i + 1 < n:
+            out.append(i + 1)
+        return out
+
+    # ---- transfer: state = frozenset of registers that may be in flight BEFORE instruction i
+    state = [None] * n
+    state[0] = frozenset()
+    work = [0]
+    bad_lines = {}
+    while work:
+        i = work.pop()
+        cur = set(state[i])
+        k, code, asm = insts[i]
+        body = code.split(";")[0]
+        if asm and body.strip().startswith("buffer_load"):
+            mm = re.search(r"buffer_load_dwordx4\s+(v\[\d+:\d+\])", body)
+            if mm:
+                cur |= regs_of(mm.group(1))
+        elif asm and "s_waitcnt vmcnt" in body:
+            named = regs_of(code.split(";", 1)[1]) if ";" in code else set(cur)
+            cur -= named
+        else:
+            hit = regs_of(body) & cur
+            if hit:
+                bad_lines[k] = code
+        new = frozenset(cur)
+        for j in succ(i):
+            merged = new if state[j] is None else (state[j] | new)
+            if merged != state[j]:
+                state[j] = merged
+                work.append(j)
+    for k in sorted(bad_lines):
+        print(f"{name}: line {k}: `{bad_lines[k]}` touches registers that may be in flight there")
+    return len(bad_lines)
+
+
 def main(path: str, prefix: str = r"_ZN3wfa11k_sg_runs32") -> int:
     txt = open(path).read()
     bad = 0
@@ -74,6 +150,10 @@ def main(path: str, prefix: str = r"_ZN3wfa11k_sg_runs32") -> int:
             bad += 1
         lines = fn.split("\n")
         bad += dot_hazards(name, lines)
+        if re.search(r"s_waitcnt vmcnt\(\d+\) ; v\[\d+:\d+\]", fn):
+            # the waits name their registers: the data-flow form covers every path (the linear walk below follows file order)
+            bad += flow_audit(name, lines)
+            continue
         i = 0
         while i < len(lines):
             if ";;#ASMSTART" in lines[i]:
