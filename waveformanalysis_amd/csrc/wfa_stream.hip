@@ -98,22 +98,26 @@ __device__ __forceinline__ uint32_t udot2_acc(uint32_t pair, uint32_t acc) {
 // 3 waves per SIMD: 168 vector registers; the kernel must not spill (the in-flight tile registers would be spilled with
 // whatever they hold at that moment)
 constexpr int kRunsOcc = 3;
+#ifndef WFA_RUNS_BLOCK
+#define WFA_RUNS_BLOCK 256
+#endif
+constexpr int kRunsBlock = WFA_RUNS_BLOCK, kRunsWaves = kRunsBlock / kWave;
 template <int W, int BLW>
-__global__ __launch_bounds__(kBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {
+__global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) {  // (threads per block, waves per SIMD)
     constexpr int H = W / 2;
     static_assert(W % 2 == 1 && W >= 5 && W <= 11, "halo of 6 samples per side");
     static_assert(BLW == 0 || BLW == 40, "in-stream baseline window");
-    __shared__ __attribute__((aligned(16))) StreamLds s_lds[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) StreamLds s_lds[kRunsWaves];
     __shared__ int32_t etab[2 * H * W];
     extern __shared__ uint32_t s_words[];  // [kWavesPerBlock][rs * wstride]
-    for (int k = threadIdx.x; k < 2 * H * W; k += kBlock) etab[k] = a.itab[W + k];
+    for (int k = threadIdx.x; k < 2 * H * W; k += kRunsBlock) etab[k] = a.itab[W + k];
     __syncthreads();
     const int lane = lane_id();
     StreamLds* __restrict__ lds = &s_lds[wave_in_block()];
     const int wstride = a.wstride;
     uint32_t* __restrict__ words = s_words + wave_in_block() * (a.rs * wstride);
-    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block());
-    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kRunsWaves + wave_in_block());
+    const int64_t nwaves = (int64_t)gridDim.x * kRunsWaves;
     const int L = a.L;
     const int S = a.S;
     const int nw = S >> 5;   // mask words per record
@@ -567,21 +571,21 @@ bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_st
 }
 
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a) {
-    int64_t g = (a.n_spans + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t g = (a.n_spans + kRunsWaves - 1) / kRunsWaves;
     // one span per wave up to 64 rounds of the resident set: the dispatcher evens out the tail best with the smallest
     // blocks (v1725, 19 531 spans: 3 / 8 rounds / one span per wave = 0.514 / 0.502 / 0.499 ms in one run; persistent
     // waves with a hand-balanced last round of smaller spans: 0.53; spans of 32 records: 0.60-0.64 -- a span's fixed
     // costs, prologue + first tile + flush, are ~19 us of its 86)
     const int rounds = 64;
-    const int64_t resident = (int64_t)rounds * 256 * kRunsOcc;
+    const int64_t resident = (int64_t)rounds * 256 * kRunsOcc * 4 / kRunsWaves;
     if (g < 1) g = 1;
     if (g > resident) g = resident;
     const int grid = (int)g;
-    const size_t dyn = (size_t)kWavesPerBlock * a.rs * a.wstride * sizeof(uint32_t);  // <= 4 x 8.5 KiB
+    const size_t dyn = (size_t)kRunsWaves * a.rs * a.wstride * sizeof(uint32_t);  // <= 4 x 8.5 KiB
 #define WFA_RUNS32(WW)                                                                                           \
     case WW:                                                                                                     \
-        if (fused_baseline) hipLaunchKernelGGL((k_sg_runs32<WW, 40>), dim3(grid), dim3(kBlock), dyn, st, a);     \
-        else hipLaunchKernelGGL((k_sg_runs32<WW, 0>), dim3(grid), dim3(kBlock), dyn, st, a);                     \
+        if (fused_baseline) hipLaunchKernelGGL((k_sg_runs32<WW, 40>), dim3(grid), dim3(kRunsBlock), dyn, st, a); \
+        else hipLaunchKernelGGL((k_sg_runs32<WW, 0>), dim3(grid), dim3(kRunsBlock), dyn, st, a);                 \
         break;
     switch (a.W) {
         WFA_RUNS32(5)
