@@ -3,9 +3,8 @@ losing or corrupting a hit (reference: hit_finder.py:329-413, the runs of `sig >
 
 * its run events are (record in span << 16) | sample: uniform records whose stride does not fit 16 bits are not
   taken at all (the build before refused nothing above L = 64 and silently mis-sorted events from L = 65 536 on);
-* a span buffers 1024 events per wave in LDS: a span with more raises flag 1, the pass is redone on the bitmap route
-  for this upload, and the next upload tries the streaming kernel again.  (Flag 2 -- the patched events of a span
-  outgrow its 2048-event slot -- needs more than 1024 + 64 * 2 * (H + 1) events and is unreachable for W <= 11.)
+* a span's events go to its 2048-event slot of the event buffer: a span with more raises flag 1, the pass is redone on
+  the bitmap route for this upload, and the next upload tries the streaming kernel again.
 """
 
 import numpy as np
@@ -77,12 +76,12 @@ def test_uniform_records_around_the_16_bit_event_limit(L, fused_baseline):
 
 
 def test_event_overflow_of_a_span_falls_back_and_recovers():
-    """thr = 1.0 on sigma = 3 noise: ~4000 runs per 64-record span, four times what a wave buffers."""
+    """thr = 1.0 on sigma = 3 noise: ~4000 runs per 64-record span, four times what a span's event slot holds."""
     rec, pool = synth.make_run(640, "v1725", cfg=5)
     filt = O.filter_wave_pool(rec, pool)
     want_low = O.threshold_hits_chunked(rec, filt, threshold=1.0)
     per_span = np.bincount(np.searchsorted(rec["record_id"], want_low["record_id"]) // 64, minlength=10)
-    assert per_span.min() > 1024, per_span   # > 512 hits = 1024 events in every span
+    assert per_span.min() > 1024, per_span   # > 1024 hits = more than the 2048 events of a slot, in every span
     with DeviceSession(0) as sess:
         sess.upload_pool(pool)
         sess.set_sg_plan(11, 2)
