@@ -92,7 +92,13 @@ def test_one_walk_and_two_walk_candidate_paths(sess):
         sess.profile(True)
         got = sess.find_peaks(_lib.SRC_F32, **cfg)
         names = set(sess.profile_report())
-        assert "k_find_peaks_staged" in names and route in names, names      # uniform records: the LDS-staged walk
+        assert "k_find_peaks_hot" in names and route in names, names         # uniform records: LDS-staged, height prefilter
+        sess.set_option("no_peak_hot", True)
+        sess.profile(True)
+        every_sample = sess.find_peaks(_lib.SRC_F32, **cfg)
+        assert "k_find_peaks_staged" in set(sess.profile_report())            # the plateau machine over every sample
+        sess.set_option("no_peak_hot", False)
+        assert every_sample.tobytes() == got.tobytes()
         sess.set_option("no_span", True)
         sess.profile(True)
         per_record = sess.find_peaks(_lib.SRC_F32, **cfg)
@@ -172,3 +178,60 @@ def test_staged_candidate_walk_over_record_lengths(sess, L, n):
             sess.set_option("no_span", True)
             assert sess.find_peaks(src, **cfg).tobytes() == got.tobytes()
             sess.set_option("no_span", False)
+            sess.set_option("no_peak_hot", True)
+            assert sess.find_peaks(src, **cfg).tobytes() == got.tobytes()
+            sess.set_option("no_peak_hot", False)
+
+
+@pytest.mark.parametrize("dense,polarity", [(0, "negative"), (0, "positive"), (1, "negative"), (2, "negative")])
+def test_height_prefilter_at_the_boundary(sess, dense, polarity):
+    """k_find_peaks_hot runs the plateau machine only on chunks that may hold a detection value >= `height`, decided in
+    float32.  Raw uint16 samples give integer detection values, long plateaus and ties: heights that ARE detection values
+    (>= must keep them), heights half a step off, a height no value reaches, and plateaus that cross chunk and record
+    ends.  Rows equal the oracle's and the bytes of the every-sample walk, for the records branch and both dense-row forms."""
+    rng = np.random.default_rng(77 + dense)
+    L, n = 160, 400
+    rec, _ = synth.make_run(n, "v1725", cfg=3, L=L)
+    w = np.full((n, L), 8000, dtype=np.int64) + rng.integers(-1, 2, size=(n, L))
+    for r in range(n):
+        for _ in range(3):
+            t0, wid, amp = int(rng.integers(2, L - 40)), int(rng.integers(1, 30)), int(rng.integers(2, 40))
+            w[r, t0:t0 + wid] -= amp                      # flat-bottomed pulses: plateaus of the signal and of its slope
+        if r % 5 == 0:
+            w[r, L - 9:] -= 25                            # a step that stays open at the record's end
+        if r % 7 == 0:
+            w[r, :3] -= 30
+    pool = w.astype(np.uint16).reshape(-1)
+    rec["baseline"] = 8000.0 + (np.arange(n) % 3) * 0.25
+    rec["polarity"] = polarity                             # one polarity class per upload: the uniform-layout routes need it
+    f32 = pool.astype(np.float32)
+    for src, p in ((_lib.SRC_RAW, pool), (_lib.SRC_F32, f32)):
+        sess.upload_pool(p)
+        sess.upload_records(rec, 0.0)
+        for cfg in (dict(height=25.0, prominence=0.0, width=0), dict(height=24.5, prominence=0.0, width=0),
+                    dict(use_derivative=False, height=25.0, prominence=0.0, width=0),
+                    dict(use_derivative=False, height=24.75, prominence=1.0, width=1),
+                    dict(use_derivative=False, height=2.0, prominence=0.0, width=0, threshold=1.0),
+                    dict(height=1.0, prominence=0.0, width=0, threshold=1.0),
+                    dict(height=1e7, prominence=0.0, width=0)):
+            sess.profile(True)
+            got = sess.find_peaks(src, dense_rows=dense, **cfg)
+            assert "k_find_peaks_hot" in set(sess.profile_report())
+            sess.set_option("no_peak_hot", True)
+            assert sess.find_peaks(src, dense_rows=dense, **cfg).tobytes() == got.tobytes(), (src, cfg)
+            sess.set_option("no_peak_hot", False)
+            if dense == 2:      # the streaming detector's float64 rows: covered against its oracle in test_hip_streaming
+                continue
+            if dense:
+                st = np.zeros(n, dtype=[("wave", p.dtype if src == _lib.SRC_F32 else np.int16, (L,)), ("baseline", "f8"),
+                                        ("dt", "i4"), ("timestamp", "i8"), ("board", "i2"), ("channel", "i2"),
+                                        ("record_id", "i8"), ("event_length", "i4")])
+                st["wave"] = p.reshape(n, L)
+                for f in ("baseline", "dt", "timestamp", "board", "channel", "record_id", "event_length"):
+                    st[f] = rec[f]
+                want = O.find_peak_hits_dense(st, **cfg)
+            else:
+                want = O.find_peak_hits(rec, p, **cfg)
+            assert len(want) == 0 if cfg["height"] > 1e6 else (len(want) > 0 or polarity == "positive")
+            G.assert_struct_equal(got, want, what=f"dense {dense} src {src} {cfg}")
+    sess.profile(False)

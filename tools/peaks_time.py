@@ -1,22 +1,36 @@
-"""Where find_peaks spends its time at the bench size: scan only (no candidates) vs default options."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import time
-import numpy as np
-from waveformanalysis_amd import _lib, synth
-from waveformanalysis_amd.device import DeviceSession
+#!/usr/bin/env python3
+"""Kernel times of the find_peaks hit detector on the bench chunk (1.25e6 x 800 samples, filtered float32 pool, reference
+default options), per route: default, `no_peak_hot` (plateau machine over every sample)."""
+import json
+import sys
 
-rec, pool = synth.make_run(1250000 // 4, "v1725", cfg=1)
-s = DeviceSession(0)
-s.upload_pool(pool)
-s.upload_records(rec, 10.0)
-s.set_sg_plan(11, 2)
-s.savgol(download=False)
-s.profile(True)
-for name, kw in (("scan only (height 1e9)", dict(height=1e9)), ("defaults", dict()),
-                 ("plain signal, height 40", dict(use_derivative=False, height=40.0, width=3, prominence=5.0))):
-    s.profile_reset() if hasattr(s, "profile_reset") else None
-    t0 = time.perf_counter()
-    out = s.find_peaks(_lib.SRC_F32, **kw)
-    dt = time.perf_counter() - t0
-    print(name, len(out), "peaks", round(dt * 1e3, 2), "ms wall", {k: round(v[0] / max(v[1], 1), 3) for k, v in s.profile_report().items() if "peaks" in k})
+import numpy as np
+
+sys.path.insert(0, ".")
+from waveformanalysis_amd import _lib, synth  # noqa: E402
+from waveformanalysis_amd.device import DeviceSession  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
+rec, pool = synth.make_run(n, "v1725", cfg=1)
+out = {}
+with DeviceSession(0) as sess:
+    sess.upload_pool(pool)
+    sess.set_sg_plan(11, 2)
+    sess.upload_records(rec, 10.0)
+    sess.savgol(download=False)
+    ref = None
+    for route in ("default", "no_peak_hot"):
+        sess.set_option("no_peak_hot", route == "no_peak_hot")
+        sess.find_peaks(_lib.SRC_F32)
+        sess.profile(True)
+        for _ in range(3):
+            rows = sess.find_peaks(_lib.SRC_F32)
+        rep = sess.profile_report()
+        out[route] = {k: round(v[0] / v[1], 4) for k, v in rep.items()}
+        out[route]["total_ms"] = round(sum(v[0] / v[1] for v in rep.values()), 4)
+        out[route]["rows"] = len(rows)
+        if ref is None:
+            ref = rows.tobytes()
+        else:
+            out["same_bytes"] = ref == rows.tobytes()
+print(json.dumps(out, indent=1))

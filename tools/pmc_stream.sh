@@ -1,4 +1,5 @@
-# SQ counters of the streaming kernel (k_sg_runs32) under bench.py, per 2048-sample tile (488281.25 tiles per launch of the default chunk)
+# SQ counters of one kernel (PMC_KERNEL, default the streaming kernel k_sg_runs32) under bench.py or PMC_SCRIPT, per unit
+# (PMC_DIV units per launch; default 488281.25 = the 2048-sample tiles of the default chunk)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmcS
 i=0
@@ -8,7 +9,7 @@ for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcS/p$i
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmcS/p$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-features ${PMC_BENCH_ARGS:-} > /dev/null 2> gpurun_out/pmcS/p$i.err || { tail -3 gpurun_out/pmcS/p$i.err; }
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmcS/p$i -- python3 ${PMC_SCRIPT:-bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-features} ${PMC_BENCH_ARGS:-} > /dev/null 2> gpurun_out/pmcS/p$i.err || { tail -3 gpurun_out/pmcS/p$i.err; }
   find gpurun_out/pmcS/p$i -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/pmcS/p$i.csv || true
   rm -rf gpurun_out/pmcS/p$i
 done

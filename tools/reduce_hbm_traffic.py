@@ -16,7 +16,7 @@ NAMES = [
     ("k_hit_rows_grp", "k_hit_rows_grp"), ("k_hit_rows_flat", "k_hit_rows_flat"), ("k_hit_rows_literal", "k_hit_rows_literal"), ("k_savgol_span", "k_savgol_span"),
     ("k_features_leaf<0", "k_basic_features_leaf"), ("k_features_leaf<1", "k_width_integral_leaf"),
     ("k_features_leaf<2", "k_features_both_leaf"), ("k_width_ties", "k_width_ties"),
-    ("k_find_peaks_staged", "k_find_peaks_staged"), ("k_find_peaks_slots", "k_find_peaks_slots"), ("k_peak_compact", "k_peak_compact"), ("k_peak_eval", "k_peak_eval"),
+    ("k_find_peaks_hot", "k_find_peaks_hot"), ("k_find_peaks_staged", "k_find_peaks_staged"), ("k_find_peaks_slots", "k_find_peaks_slots"), ("k_peak_compact", "k_peak_compact"), ("k_peak_eval", "k_peak_eval"),
     ("k_peak_rows", "k_peak_rows"),
 ]
 

@@ -785,6 +785,7 @@ int wfa_set_option(wfa_ctx* c, const char* name, int value) {
     else if (n == "no_runs32") c->opt.no_runs32 = v;
     else if (n == "no_speculate") c->opt.no_speculate = v;
     else if (n == "no_peak_slots") c->opt.no_peak_slots = v;
+    else if (n == "no_peak_hot") c->opt.no_peak_hot = v;
     else if (n == "rows_grouped") c->opt.rows_grouped = v;
     else return fail(WFA_E_INVALID, "unknown option '%s'", name);
     return WFA_OK;
@@ -1288,14 +1289,20 @@ int wfa_find_peaks_count(wfa_ctx* c, int source, int signal_mode, int use_deriva
             LaunchTimer t(c);
             hipError_t herr = hipSuccess;
             // uniform records: the walk on LDS-staged groups (coalesced); any other layout: one lane per record
-            const bool staged = c->span_ok && !c->opt.no_span &&
+            // uniform records: LDS-staged groups (coalesced) -- the plateau machine only on the chunks that can hold a value
+            // >= `height` (k_find_peaks_hot), or over every sample (k_find_peaks_staged)
+            const bool hot = c->span_ok && !c->opt.no_span && !c->opt.no_peak_hot &&
+                             launch_find_peaks_hot(c->stream, source, pv, rv, pp, c->span_off0, c->span_L, K, counts,
+                                                   c->peak_slot_pos.as<int32_t>(), c->peak_slot_val.as<double>(), overflow, &herr);
+            WFA_HIP_CHECK(herr);
+            const bool staged = !hot && c->span_ok && !c->opt.no_span &&
                                 launch_find_peaks_staged(c->stream, source, pv, rv, pp, c->span_off0, c->span_L, K, counts,
                                                          c->peak_slot_pos.as<int32_t>(), c->peak_slot_val.as<double>(), overflow, &herr);
             WFA_HIP_CHECK(herr);
-            if (!staged)
+            if (!staged && !hot)
                 WFA_HIP_CHECK(launch_find_peaks_slots(c->stream, source, pv, rv, pp, K, counts, c->peak_slot_pos.as<int32_t>(),
                                                       c->peak_slot_val.as<double>(), overflow));
-            if ((rc = t.end(staged ? "k_find_peaks_staged" : "k_find_peaks_slots"))) return rc;
+            if ((rc = t.end(hot ? "k_find_peaks_hot" : staged ? "k_find_peaks_staged" : "k_find_peaks_slots"))) return rc;
         } else {
             LaunchTimer t(c);
             WFA_HIP_CHECK(launch_find_peaks(c->stream, source, false, pv, rv, pp, counts, nullptr, nullptr, nullptr, nullptr));

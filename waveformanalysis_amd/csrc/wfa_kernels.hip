@@ -2334,16 +2334,13 @@ __device__ __forceinline__ void stream_det(const SigT& S, int i_start, const F& 
     bool have_carry = false, active = true;
     int64_t c = (S.off0 + k0) >> 3;
     const int64_t c_lo = S.off0 >> 3, c_hi = (S.off0 + S.L - 1) >> 3;
-    while (active && c >= c_lo && c <= c_hi) {
-        double wd[8];
-        float wf[8];
-        load_chunk<SRC>(S.pv, c, wd, wf);
-        const int kb = (int)(c * 8 - S.off0);
+    auto consume = [&](int64_t cq, const float (&wf)[8]) __attribute__((always_inline)) {
+        const int kb = (int)(cq * 8 - S.off0);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = DIR > 0 ? jj : 7 - jj;
             const int k = kb + j;
-            const bool in = DIR > 0 ? (k >= k0 && k < S.L) : (k <= k0 && k >= 0);
+            const bool in = DIR > 0 ? (k >= k0 && k < S.L) : (k <= k0 && k >= 0);  // false for a chunk outside the record
             if (active && in) {
                 const float w = wf[j];
                 if (!deriv) {
@@ -2357,7 +2354,28 @@ __device__ __forceinline__ void stream_det(const SigT& S, int i_start, const F& 
                 }
             }
         }
-        c += DIR;
+    };
+    // Two chunks (16 samples) per step, the next two requested before these are consumed: every step of this walk used to
+    // wait for its own cache line, and a launch of k_peak_eval is as long as its longest chain of such waits (all of its
+    // waves are resident at once).  Chunks past the record's ends are read from the clamped address and masked.
+    auto pick = [&](int64_t q) { return q < c_lo ? c_lo : (q > c_hi ? c_hi : q); };
+    float a0[8], a1[8], b0[8], b1[8];
+    double wd[8];
+    load_chunk<SRC>(S.pv, pick(c), wd, a0);
+    load_chunk<SRC>(S.pv, pick(c + DIR), wd, a1);
+    for (;;) {
+        load_chunk<SRC>(S.pv, pick(c + 2 * DIR), wd, b0);
+        load_chunk<SRC>(S.pv, pick(c + 3 * DIR), wd, b1);
+        consume(c, a0);
+        consume(c + DIR, a1);
+        c += 2 * DIR;
+        if (!active || c < c_lo || c > c_hi) break;
+        load_chunk<SRC>(S.pv, pick(c + 2 * DIR), wd, a0);
+        load_chunk<SRC>(S.pv, pick(c + 3 * DIR), wd, a1);
+        consume(c, b0);
+        consume(c + DIR, b1);
+        c += 2 * DIR;
+        if (!active || c < c_lo || c > c_hi) break;
     }
 }
 
@@ -2785,6 +2803,243 @@ __global__ __launch_bounds__(kWave) void k_find_peaks_staged(PoolView pool, RecV
     }
 }
 
+// The candidate walk with the exact plateau machine run only where it can matter.  Every candidate scipy keeps passes
+// `height`: its plateau value is >= hmin, so its plateau STARTS at a detection value >= hmin.  A wave reads a group of
+// consecutive uniform records (16 KiB, 16-byte pieces, every byte of the pool once) and tests each piece in registers, in
+// float32 (two or three instructions per sample), for a value that may reach hmin -- a test that can only err towards
+// "hot" (launch_find_peaks_hot derives the float32 bound h32).  The float64 machine of k_find_peaks_staged then runs with a
+// lane per HOT piece, reading its few samples back through L2: it finds the candidates whose plateau starts in its piece,
+// exactly as a lane of the staged kernel does for its stretch.  With the reference's default height (30 on the derivative of
+// a filtered waveform) one piece in ~200 is hot.  Same slots, counts and overflow flag as the staged kernel.
+struct HotPeakArgs {
+    int64_t off0;   // first sample of record 0 in the pool
+    int32_t L;      // samples per record (multiple of 8)
+    int32_t RW;     // records per wave
+    float h32;      // float32 bound of `height`
+    float inv_ppr;  // 1 / (pieces per record)
+};
+constexpr int kHotWaves = 4;  // waves per block, each with its own group
+
+template <int SRC>
+__global__ __launch_bounds__(kHotWaves * kWave) void k_find_peaks_hot(PoolView pool, RecView rec, PeakParams pp, HotPeakArgs ha,
+                                                                      int K, int32_t* __restrict__ counts,
+                                                                      int32_t* __restrict__ slot_pos,
+                                                                      double* __restrict__ slot_val, int* __restrict__ overflow) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int ES = SRC == WFA_SRC_RAW ? 2 : 4;
+    constexpr int PIECE = 16 / ES;  // samples per 16-byte piece
+    constexpr int kRounds = 16;     // pieces per lane: 1024 per wave
+    __shared__ uint16_t s_hot_all[kHotWaves][kRounds * kWave];
+    struct RecKey { float b32; uint32_t sgn; };  // float32 baseline, sign bit of "signal = -(w - baseline)"
+    __shared__ double s_bl_all[kHotWaves][2 * kWave];  // (a lane past the group's last piece reads up to 63 records further)
+    __shared__ RecKey s_key_all[kHotWaves][2 * kWave];
+    __shared__ int s_cnt_all[kHotWaves][kWave];
+    const int lane = lane_id(), wave = wave_in_block();
+    uint16_t* s_hot = s_hot_all[wave];
+    double* s_bl = s_bl_all[wave];
+    RecKey* s_key = s_key_all[wave];
+    int* s_cnt = s_cnt_all[wave];
+    const int L = ha.L, RW = ha.RW;
+    const int ppr = L / PIECE;  // pieces per record
+    const int64_t r0 = ((int64_t)blockIdx.x * kHotWaves + wave) * RW;
+    if (r0 >= rec.R) return;  // (no block-wide barrier below: the waves are independent)
+    const int nrec = (int)(rec.R - r0 < RW ? rec.R - r0 : RW);
+    const int pieces = nrec * ppr;  // <= 1024
+    u4 pf[kRounds];
+    {
+        const u4* __restrict__ src = reinterpret_cast<const u4*>(SRC == WFA_SRC_RAW ? (const void*)pool.u16 : (const void*)pool.f32) +
+                                     (ha.off0 * ES >> 4) + r0 * ppr;
+#pragma unroll
+        for (int t = 0; t < kRounds; ++t) {
+            const int c = t * kWave + lane;
+            pf[t] = src[c < pieces ? c : 0];
+        }
+        {
+            const int64_t q = lane < nrec ? r0 + lane : r0;
+            const double bl = rec.baseline[q];
+            const uint32_t sgn = rec.pol[q] == WFA_POL_POSITIVE ? 0u : 0x80000000u;
+            s_bl[lane] = bl; s_bl[kWave + lane] = bl;
+            s_key[lane] = RecKey{(float)bl, sgn}; s_key[kWave + lane] = RecKey{(float)bl, sgn};
+            s_cnt[lane] = 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int deriv = pp.use_derivative;
+    const int n = deriv ? L - 1 : L;
+    if (n < 3) {
+        if (lane < nrec) counts[r0 + lane] = 0;
+        return;
+    }
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint16_t* gu = pool.u16 ? pool.u16 + ha.off0 + r0 * L : nullptr;
+    const float* gf = pool.f32 ? pool.f32 + ha.off0 + r0 * L : nullptr;
+    auto sample = [&](int t, int j) -> float {  // sample j of this lane's piece of round t
+        if constexpr (SRC == WFA_SRC_RAW) return (float)((pf[t][j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        else return __uint_as_float(pf[t][j]);
+    };
+
+    // make_hot(g)(w0, w1): may the detection value of samples (w0, w1) of record g be >= hmin?   make_det(g)(w0, w1): the value.
+    auto run = [&](auto make_hot, auto make_det, auto deriv_tag) __attribute__((always_inline)) {
+        constexpr int DERIV = decltype(deriv_tag)::value;
+        // ---- pass 1: hot pieces, in (record, position) order.  (g, a) = record and first sample of the lane's piece,
+        // advanced by 64 pieces per round; no branches: this loop is the kernel's instruction count
+        int n_hot = 0;
+        int g = (int)(((float)lane + 0.5f) * ha.inv_ppr);
+        int a = (lane - g * ppr) * PIECE;
+        const int wraps = (kWave + ppr - 1) / ppr;  // records a lane can cross per round
+#pragma unroll
+        for (int t = 0; t < kRounds; ++t) {
+            if (t * kWave >= pieces) break;
+            float w[PIECE + 1];
+#pragma unroll
+            for (int j = 0; j < PIECE; ++j) w[j] = sample(t, j);
+            if constexpr (DERIV) {
+                // the sample behind the piece: the next lane's first one (lane 63: lane 0 of the next round); the last piece
+                // of a record does not use it (its last sample is no detection index of the derivative)
+                const uint32_t wrap = (uint32_t)__builtin_amdgcn_readlane(__builtin_bit_cast(int, sample(t + 1 < kRounds ? t + 1 : t, 0)), 0);
+                w[PIECE] = __uint_as_float(dpp_from_next_lane(wrap, __float_as_uint(w[0])));
+            } else {
+                w[PIECE] = 0.f;
+            }
+            const auto hot32 = make_hot(g);
+            bool hot = false;
+#pragma unroll
+            for (int j = 0; j < PIECE - 1; ++j) hot |= hot32(w[j], w[j + 1]);
+            hot |= hot32(w[PIECE - 1], w[PIECE]) & (!DERIV || a + PIECE < L);
+            hot &= t * kWave + lane < pieces;
+            const uint64_t m = __ballot(hot);
+            if (m != 0) {
+                if (hot) s_hot[n_hot + __popcll(m & lt_mask)] = (uint16_t)(t * kWave + lane);
+                n_hot += __popcll(m);
+            }
+            a += kWave * PIECE;
+            for (int q = 0; q < wraps; ++q) {
+                const bool over = a >= L;
+                a -= over ? L : 0;
+                g += over ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- pass 2: the plateau machine, a lane per hot piece (samples through L2: the wave has just read them)
+        for (int e0 = 0; e0 < n_hot; e0 += kWave) {
+            const bool act = e0 + lane < n_hot;
+            const int c = act ? (int)s_hot[e0 + lane] : 0;
+            const int g = (int)(((float)c + 0.5f) * ha.inv_ppr);
+            const int a = act ? (c - g * ppr) * PIECE : 0;
+            const int b = act ? (a + PIECE < n ? a + PIECE : n) : 0;
+            const int gb = g * L;
+            auto wv = [&](int m) { return SRC == WFA_SRC_RAW ? (float)gu[gb + m] : gf[gb + m]; };
+            const auto det2 = make_det(g);
+            constexpr int kStash = 4;  // plateau starts are two samples apart: at most four in a piece
+            int n_mine = 0;
+            int st_pos[kStash] = {0, 0, 0, 0};
+            double st_val[kStash] = {0.0, 0.0, 0.0, 0.0};
+            auto on_peak = [&](int c_start, int i, double c_val) {  // plateau [c_start, i - 1] ended by a fall at i
+                const int peak = (c_start + i - 1) / 2;
+                bool keep = c_val >= pp.hmin;
+                if (keep && pp.has_threshold) {
+                    const double lt = c_val - det2(wv(peak - 1), DERIV ? wv(peak) : 0.f);
+                    const double rt = c_val - det2(wv(peak + 1), DERIV ? wv(peak + 2 < L ? peak + 2 : L - 1) : 0.f);
+                    keep = (lt < rt ? lt : rt) >= pp.tmin;
+                }
+                if (keep) {
+#pragma unroll
+                    for (int q = 0; q < kStash; ++q)
+                        if (n_mine == q) { st_pos[q] = peak; st_val[q] = c_val; }
+                    ++n_mine;
+                }
+            };
+            bool have = false;
+            int c_start = 0;
+            double c_val = 0.0;
+            // samples a - 1 .. a + PIECE of the record (clamped), all requested before the first is used
+            float ws[PIECE + 2];
+#pragma unroll
+            for (int j = 0; j < PIECE + 2; ++j) {
+                const int m = a - 1 + j;
+                ws[j] = wv(m < 0 ? 0 : (m < L ? m : L - 1));
+            }
+            double x_prev = a > 0 ? det2(ws[0], DERIV ? ws[1] : 0.f) : 0.0;
+#pragma unroll
+            for (int u = 0; u < PIECE; ++u) {
+                const int i = a + u;
+                const double x = det2(ws[u + 1], DERIV ? ws[u + 2] : 0.f);
+                const bool in = i < b;
+                const bool actv = in && i > 0;
+                const bool fall = actv && have && x < c_val;
+                if (fall) on_peak(c_start, i, c_val);
+                const bool set = actv && (have ? x > c_val : (x_prev < x && i < n - 1));
+                have = (have && !fall) || (actv && set);
+                c_start = set ? i : c_start;
+                c_val = set ? x : c_val;
+                x_prev = in ? x : x_prev;
+            }
+            for (int i = b; __ballot(have && i < n) != 0; ++i) {  // an open candidate is followed to its end
+                const bool go = have && i < n;
+                const int m = go ? i : 0;
+                const double x = det2(wv(m), DERIV ? wv(m + 1 < L ? m + 1 : L - 1) : 0.f);
+                if (go && x < c_val) on_peak(c_start, i, c_val);
+                have = go && x == c_val;  // a fall ends it as a peak, a rise as the start of a later piece's plateau
+            }
+            // slots: candidates of a record in position order = in lane order, continuing the record's earlier batches
+            const int gk = act ? g : kWave;
+            int tot;
+            const int excl = wave_excl_scan_i32(n_mine, tot);
+            const int gprev = __shfl_up(gk, 1, kWave);
+            const int gnext = __shfl_down(gk, 1, kWave);
+            const uint64_t heads = __ballot(lane == 0 || gk != gprev);
+            const int hl = 63 - __builtin_clzll(heads & (lt_mask | (1ull << lane)));
+            const int slot0 = (act ? s_cnt[g] : 0) + excl - __shfl(excl, hl, kWave);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (act) {
+                const int64_t sb = (r0 + g) * K;
+#pragma unroll
+                for (int q = 0; q < kStash; ++q)
+                    if (n_mine > q && slot0 + q < K) { slot_pos[sb + slot0 + q] = st_pos[q]; slot_val[sb + slot0 + q] = st_val[q]; }
+                if (lane == kWave - 1 || gk != gnext) s_cnt[g] = slot0 + n_mine;
+                if (n_mine > kStash) atomicOr(overflow, 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
+    {
+        const float h32 = ha.h32;
+        const double hmin = pp.hmin;
+        auto rec32 = [](float w, float b32, uint32_t sgn) { return __uint_as_float(__float_as_uint(w - b32) ^ sgn); };
+        if (!pp.rows) {
+            if (deriv)
+                run([&](int g) { const RecKey k = s_key[g];
+                                 return [=](float w0, float w1) { return rec32(w1, k.b32, k.sgn) - rec32(w0, k.b32, k.sgn) >= h32; }; },
+                    [&](int g) { const RecKey k = s_key[g];
+                                 return [=](float w0, float w1) { return (double)rec32(w1, k.b32, k.sgn) - (double)rec32(w0, k.b32, k.sgn); }; },
+                    std::integral_constant<int, 1>{});
+            else
+                run([&](int g) { const RecKey k = s_key[g];
+                                 return [=](float w0, float) { return rec32(w0, k.b32, k.sgn) >= h32; }; },
+                    [&](int g) { const RecKey k = s_key[g];
+                                 return [=](float w0, float) { return (double)rec32(w0, k.b32, k.sgn) - 0.0; }; },
+                    std::integral_constant<int, 0>{});
+        } else if (!deriv) {
+            run([&](int g) { const double b64 = s_bl[g]; return [=](float w0, float) { return b64 - (double)w0 >= hmin; }; },
+                [&](int g) { const double b64 = s_bl[g]; return [=](float w0, float) { return b64 - (double)w0; }; },
+                std::integral_constant<int, 0>{});
+        } else if (SRC == WFA_SRC_RAW || pp.rows == WFA_PEAK_SIGNAL_ROWS_F64) {
+            run([&](int) { return [=](float w0, float w1) { return -(w1 - w0) >= h32; }; },
+                [&](int) { return [=](float w0, float w1) { return -((double)w1 - (double)w0); }; },
+                std::integral_constant<int, 1>{});
+        } else {
+            run([&](int) { return [=](float w0, float w1) { return -(w1 - w0) >= h32; }; },
+                [&](int) { return [=](float w0, float w1) { return (double)(-(w1 - w0)); }; },
+                std::integral_constant<int, 1>{});
+        }
+    }
+    if (lane < nrec) {
+        const int tot = s_cnt[lane];
+        counts[r0 + lane] = tot;
+        if (tot > K) atomicOr(overflow, 1);
+    }
+}
+
 __global__ __launch_bounds__(kPeakBlock) void k_peak_compact(int64_t R, int K, const int32_t* __restrict__ counts,
                                                              const int64_t* __restrict__ cand_start,
                                                              const int32_t* __restrict__ slot_pos,
@@ -3157,6 +3412,35 @@ bool launch_find_peaks_staged(hipStream_t st, int source, const PoolView& pool, 
         hipLaunchKernelGGL((k_find_peaks_staged<WFA_SRC_RAW>), dim3(grid), dim3(kWave), lds, st, pool, rec, pp, sa, K, counts, slot_pos, slot_val, overflow);
     else
         hipLaunchKernelGGL((k_find_peaks_staged<WFA_SRC_F32>), dim3(grid), dim3(kWave), lds, st, pool, rec, pp, sa, K, counts, slot_pos, slot_val, overflow);
+    *err = hipGetLastError();
+    return true;
+}
+
+// false: the layout or the parameters are not covered (the staged walk runs instead)
+bool launch_find_peaks_hot(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                           int64_t off0, int L, int K, int32_t* counts, int32_t* slot_pos, double* slot_val, int* overflow,
+                           hipError_t* err) {
+    *err = hipSuccess;
+    if (rec.R == 0 || L < 8 || (L & 7) || (off0 & 7)) return false;
+    if (source != WFA_SRC_RAW && source != WFA_SRC_F32) return false;
+    if (!std::isfinite(pp.hmin)) return false;  // no height bound: every piece would be hot
+    const int cap = source == WFA_SRC_RAW ? 8192 : 4096;  // samples per wave: 1024 pieces of 16 bytes
+    if (L > cap) return false;
+    const int RW = cap / L < kWave ? cap / L : kWave;
+    // float32 bound of `height`.  A detection value is x = fl64(d) for a real d (a difference of float32 samples, or one
+    // of them); the first pass sees k = fl32(d).  Rounding is monotonic: x >= hmin gives fl32(x) >= fl32(hmin), and fl32(d)
+    // is fl32(x) or its neighbour below (d and x differ by half a float64 ulp at most).  Two float32 steps below
+    // fl32(hmin) is therefore a bound no value that passes `height` can fall under.
+    float h32 = (float)pp.hmin;
+    h32 = std::nextafterf(std::nextafterf(h32, -INFINITY), -INFINITY);
+    const int piece = source == WFA_SRC_RAW ? 8 : 4;
+    HotPeakArgs ha{off0, L, RW, h32, 1.0f / (float)(L / piece)};
+    const int64_t groups = (rec.R + RW - 1) / RW;
+    const unsigned grid = (unsigned)((groups + kHotWaves - 1) / kHotWaves);
+    if (source == WFA_SRC_RAW)
+        hipLaunchKernelGGL((k_find_peaks_hot<WFA_SRC_RAW>), dim3(grid), dim3(kHotWaves * kWave), 0, st, pool, rec, pp, ha, K, counts, slot_pos, slot_val, overflow);
+    else
+        hipLaunchKernelGGL((k_find_peaks_hot<WFA_SRC_F32>), dim3(grid), dim3(kHotWaves * kWave), 0, st, pool, rec, pp, ha, K, counts, slot_pos, slot_val, overflow);
     *err = hipGetLastError();
     return true;
 }

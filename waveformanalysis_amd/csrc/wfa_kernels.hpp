@@ -188,6 +188,9 @@ hipError_t launch_find_peaks(hipStream_t st, int source, bool fill, const PoolVi
 constexpr int kPeakSlots = 8;  // candidates per record the single walk keeps (more: the fill walk runs)
 hipError_t launch_find_peaks_slots(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
                                    int K, int32_t* counts, int32_t* slot_pos, double* slot_val, int* overflow);
+bool launch_find_peaks_hot(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
+                           int64_t off0, int L, int K, int32_t* counts, int32_t* slot_pos, double* slot_val, int* overflow,
+                           hipError_t* err);
 bool launch_find_peaks_staged(hipStream_t st, int source, const PoolView& pool, const RecView& rec, const PeakParams& pp,
                               int64_t off0, int L, int K, int32_t* counts, int32_t* slot_pos, double* slot_val, int* overflow,
                               hipError_t* err);
