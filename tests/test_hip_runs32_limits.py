@@ -163,3 +163,44 @@ def test_flat_rows_kernel_equals_grouped_rows_kernel(preset, n):
         wide = sess.threshold_hits(_lib.SRC_SG_FUSED, 900, 900)
         G.assert_struct_equal(wide, O.threshold_hits_chunked(rec, O.filter_wave_pool(rec, pool), left_extension=900,
                                                              right_extension=900), float_rtol=1e-6, what="wide windows")
+
+
+@pytest.mark.parametrize("preset,n,L", [("v1725", 3000, None), ("vx2730", 1500, None), ("v1725", 900, 1024), ("v1725", 700, 1184)])
+@pytest.mark.parametrize("fused_baseline", [False, True])
+def test_edge_samples_from_lds_equal_edge_samples_from_memory(preset, n, L, fused_baseline):
+    """The flush evaluates the 2H edge samples of every record with the polynomial-fit rows.  Their inputs -- the first 12
+    samples (kept by the span prologue) and the 12 samples around L - W (left by the lane of the tile loop that holds the
+    record's end) -- come out of LDS by default; `no_deposit` reads the tail from memory again, and so do layouts whose
+    span image leaves no room (L = 1024) or whose padding pushes those samples out of the last lane.  Same rows."""
+    rec, pool = synth.make_run(n, preset, cfg=41) if L is None else synth.make_run(n, preset, cfg=41, L=L)
+    rng = np.random.default_rng(n)
+    w = pool.reshape(len(rec), -1).copy()
+    for r in rng.choice(len(rec), size=len(rec) // 3, replace=False):   # pulses that sit on a record's first / last samples
+        if r % 2:
+            w[r, -int(rng.integers(3, 14)):] -= np.uint16(rng.integers(60, 900))
+        else:
+            w[r, :int(rng.integers(1, 9))] -= np.uint16(rng.integers(60, 900))
+    pool = w.reshape(-1)
+    rec["baseline"] = w[:, :40].astype(np.float64).mean(axis=1)
+    want = O.threshold_hits_chunked(rec, O.filter_wave_pool(rec, pool))
+    assert np.any(want["edge_start"] == 0) and np.any(want["edge_end"] == w.shape[1])
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        up = rec.copy()
+        if fused_baseline:
+            up["baseline"] = np.nan
+        run = (lambda: sess.fused_baseline_filter_hits((0, 40), 2, 2)) if fused_baseline else \
+            (lambda: sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2))
+        sess.upload_records(up, 10.0)
+        sess.profile(True)
+        got = run()
+        assert any(k.startswith("k_sg_runs32") for k in sess.profile_report())
+        G.assert_struct_equal(got, want, float_rtol=1e-6, what=f"{preset} L={L}")
+        sess.set_option("no_deposit", True)
+        sess.upload_records(up, 10.0)
+        assert run().tobytes() == got.tobytes()
+        sess.set_option("no_deposit", False)
+        sess.set_option("span_records", 51)     # spans of fewer records than a wave has lanes (measurement option)
+        sess.upload_records(up, 10.0)
+        assert run().tobytes() == got.tobytes()

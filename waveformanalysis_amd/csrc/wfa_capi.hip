@@ -196,6 +196,7 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
     const int64_t R = c->R;
     int32_t g_wstride = 0, g_nseg = 0, g_segw = 0;
     sg_runs32_geometry(sp.S, &sp.rs, &g_wstride, &g_nseg, &g_segw);
+    if (c->opt.span_records > 0 && c->opt.span_records < sp.rs) sp.rs = c->opt.span_records;
     sp.n_spans = (R + sp.rs - 1) / sp.rs;
     const int64_t ns = sp.n_spans;
     const int64_t nb = scan_blocks_for(ns);
@@ -246,6 +247,7 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         ra.delta = std::max(4.0 * (double)sp0.guard / (8.0 * (double)sp0.den * 16777216.0), 1e-6);
         ra.W = sp0.W; ra.L = sp.L; ra.S = sp.S; ra.positive = sp.positive; ra.rs = sp.rs;
         ra.wstride = g_wstride; ra.nseg = g_nseg; ra.segw = g_segw;
+        ra.dep = (!c->opt.no_deposit && sg_runs32_deposit(sp.L, sp.S, sp0.W, sp.rs, g_wstride)) ? 1 : 0;
         ra.off0 = sp.off0; ra.n_spans = ns;
         ra.ev = rn.ev; ra.ev_cap = rn.ev_cap; ra.cursor = rn.cursor; ra.span_off = rn.span_off; ra.span_cnt = rn.span_cnt;
         ra.flags = rn.flags;
@@ -786,7 +788,9 @@ int wfa_set_option(wfa_ctx* c, const char* name, int value) {
     else if (n == "no_speculate") c->opt.no_speculate = v;
     else if (n == "no_peak_slots") c->opt.no_peak_slots = v;
     else if (n == "no_peak_hot") c->opt.no_peak_hot = v;
+    else if (n == "no_deposit") c->opt.no_deposit = v;
     else if (n == "rows_grouped") c->opt.rows_grouped = v;
+    else if (n == "span_records") c->opt.span_records = value;  // streaming kernel: records per span (0 = chosen by the library)
     else return fail(WFA_E_INVALID, "unknown option '%s'", name);
     return WFA_OK;
 }

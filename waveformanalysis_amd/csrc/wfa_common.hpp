@@ -120,6 +120,8 @@ struct wfa_ctx {
         bool no_pad = false;       // no padded shadow layout
         bool no_runs32 = false;    // bitmap route (k_sg_mask_span16 + scan + k_hit_runs) instead of k_sg_runs32
         bool no_speculate = false; // exact row launches (host round trip for the hit count)
+        bool no_deposit = false;    // streaming kernel: the flush reads the records' last samples from memory again (no LDS deposit)
+        int span_records = 0;       // streaming kernel: records per span (measurement; 0 = library's choice)
         bool no_peak_hot = false;   // find_peaks: the plateau machine over every sample (k_find_peaks_staged), no height prefilter
         bool no_peak_slots = false; // find_peaks: count + fill walks instead of one walk into per-record slots
         bool rows_grouped = false;  // hit rows: the 8-lanes-per-hit kernel instead of the flat chunk-per-lane kernel

@@ -3093,7 +3093,10 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_eval(PoolView pool, RecView
                                                           const uint8_t* __restrict__ state,
                                                           int32_t* __restrict__ accept, double* __restrict__ ips) {
     // (Handing the lanes of a wave candidates of similar height -- a radix sort by value in front -- did not pay:
-    // 1.58 ms against 1.21 ms, the walks of neighbouring candidates share cache lines.)
+    // 1.58 ms against 1.21 ms, the walks of neighbouring candidates share cache lines.  Nor did a wave-level form of the
+    // walks without a branch per sample -- both directions in one loop, every sample slot evaluated by every lane through
+    // selects: identical rows, 0.92 ms against 0.70: 201 registers, 2 waves per SIMD, and the launch is a chain of load
+    // round trips per wave, not instruction issue.)
     const int64_t k = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (k >= n_cand) return;
     int ok = 0;

@@ -108,7 +108,7 @@ struct RunsArgs {
     double delta;           // numerator units by which scipy's float64 chain may differ from the exact rational
     int32_t W, L, S, positive, rs;
     int32_t wstride, nseg, segw;  // sg_runs32_geometry: LDS words per record (odd), flush segments per record, words per segment
-    int32_t dbg;            // unused
+    int32_t dep;            // sg_runs32_deposit: the records' last lanes go to LDS in the tile loop
     int64_t off0, n_spans;
     uint32_t* ev;
     int64_t ev_cap;
@@ -220,6 +220,8 @@ hipError_t launch_sg_mask_span16(hipStream_t st, bool fused_baseline, const Pool
 bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl);
 int64_t sg_runs32_event_slot();  // events of the buffer every span owns
 void sg_runs32_geometry(int32_t S, int32_t* rs, int32_t* wstride, int32_t* nseg, int32_t* segw);
+int64_t sg_runs32_lds_words(int32_t rs, int32_t wstride, bool dep);
+bool sg_runs32_deposit(int32_t L, int32_t S, int32_t W, int32_t rs, int32_t wstride);
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a);
 hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,
                                const int64_t* span_row0, int64_t cap, int4* desc);

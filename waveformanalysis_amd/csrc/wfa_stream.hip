@@ -115,7 +115,13 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
     const int lane = lane_id();
     StreamLds* __restrict__ lds = &s_lds[wave_in_block()];
     const int wstride = a.wstride;
-    uint32_t* __restrict__ words = s_words + wave_in_block() * (a.rs * wstride);
+    // per wave: the span's bit image, then the records' first 12 samples (6 dwords each, from the prologue) and -- when
+    // a.dep -- the 64 bytes of the lane that holds each record's last samples (from the tile loop)
+    const int per_wave = a.rs * wstride + a.rs * 6 + (a.dep ? a.rs * 16 : 0);
+    uint32_t* __restrict__ words = s_words + wave_in_block() * per_wave;
+    uint32_t* __restrict__ heads = words + a.rs * wstride;
+    uint32_t* __restrict__ tails = heads + a.rs * 6;
+    const bool dep = a.dep != 0;
     const int64_t wave0 = uniform_i64((int64_t)blockIdx.x * kRunsWaves + wave_in_block());
     const int64_t nwaves = (int64_t)gridDim.x * kRunsWaves;
     const int L = a.L;
@@ -172,6 +178,9 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
                     sum = udot2_acc(h.y, sum);
                     sum = udot2_acc(h.z, sum);
                     sum = udot2_acc(h.w, sum);
+                    // the first 12 samples stay in LDS for the edge rows after the tiles
+                    if (c == 0) { heads[lane * 6 + 0] = h.x; heads[lane * 6 + 1] = h.y; heads[lane * 6 + 2] = h.z; heads[lane * 6 + 3] = h.w; }
+                    if (c == 1) { heads[lane * 6 + 4] = h.x; heads[lane * 6 + 5] = h.y; }
                 }
                 tot_l = (int)sum;
                 // tot / BLW, correctly rounded: reciprocal product + one FMA correction step (equal to the division for
@@ -182,6 +191,10 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
                 b = positive ? -q1 : q1;
             } else {
                 b = positive ? -bl_cur : bl_cur;
+                const uint32_t* __restrict__ hp =
+                    reinterpret_cast<const uint32_t*>(a.pool + g_base + (int64_t)(lane < nrec ? lane : 0) * S);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) heads[lane * 6 + k] = hp[k];
             }
             // Exact decision boundary.  The reference masks  sig = +-(b - f32(y)) >= thr, i.e. (on the signed
             // quantities used here)  f32(y) <= v  with  v = +-b - thr.  Let lo <= v < hi be the adjacent float32
@@ -251,6 +264,11 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
                 const uint32_t hr0 = hr_r.x ^ 0x80008000u, hr1 = hr_r.y ^ 0x80008000u, hr2 = hr_r.z ^ 0x80008000u;
                 const bool act = rl < nrec;
                 const int rli = act ? rl : 0;
+                // the lane that holds a record's last samples leaves its 64 bytes for the edge rows (2-3 lanes of a tile)
+                if (dep && act && i0 == S - kSpl) {
+                    wfa_v4u* __restrict__ tq = reinterpret_cast<wfa_v4u*>(tails + rl * 16);
+                    tq[0] = tile.q0; tq[1] = tile.q1; tq[2] = tile.q2; tq[3] = tile.q3;
+                }
 
                 // ---- biased samples + halo (the raw tile registers die here) ----
                 uint32_t E[22];
@@ -391,11 +409,18 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
                 uint32_t border_e = 0;
                 // 12 samples from the record's start, 12 from the even index at or in front of sample L - W
                 const int te = (L - W) & ~1, o_tail = (L - W) - te;
-                const uint32_t* __restrict__ hp = reinterpret_cast<const uint32_t*>(a.pool + g_base + (int64_t)lane * S);
-                const uint32_t* __restrict__ tp = reinterpret_cast<const uint32_t*>(a.pool + g_base + (int64_t)lane * S + te);
                 uint32_t hd[6], td[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { hd[k] = hp[k]; td[k] = tp[k]; }
+                for (int k = 0; k < 6; ++k) hd[k] = heads[lane * 6 + k];
+                if (dep) {  // [te, te + 12) lies in the record's last lane: pad <= 20 (launch_sg_runs32)
+                    const uint32_t* __restrict__ tl = tails + lane * 16 + ((te - (S - kSpl)) >> 1);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) td[k] = tl[k];
+                } else {
+                    const uint32_t* __restrict__ tp = reinterpret_cast<const uint32_t*>(a.pool + g_base + (int64_t)lane * S + te);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) td[k] = tp[k];
+                }
 #pragma unroll 1
                 for (int side = 0; side < 2; ++side) {
                     int xw[W];
@@ -559,6 +584,19 @@ void sg_runs32_geometry(int32_t S, int32_t* rs, int32_t* wstride, int32_t* nseg,
     *wstride = nw | 1;
 }
 
+// LDS words of one wave's span: bit image + record heads (+ record tails)
+int64_t sg_runs32_lds_words(int32_t rs, int32_t wstride, bool dep) { return (int64_t)rs * wstride + (int64_t)rs * 6 + (dep ? (int64_t)rs * 16 : 0); }
+
+// May the tile loop deposit the records' last lanes in LDS (instead of the flush reading those samples again from
+// memory)?  The 12 samples from the even index at or below L - W must lie in the record's last lane, and three blocks
+// must still fit a CU's 160 KiB of LDS (a fourth wave per SIMD does not exist anyway: 168 registers).
+bool sg_runs32_deposit(int32_t L, int32_t S, int32_t W, int32_t rs, int32_t wstride) {
+    const int te = (L - W) & ~1;
+    if (te < S - kSpl) return false;
+    const int64_t block_bytes = (int64_t)kRunsWaves * (sg_runs32_lds_words(rs, wstride, true) * 4 + (int64_t)sizeof(StreamLds)) + 1024;
+    return block_bytes * kRunsOcc * 4 / kRunsWaves <= 160 * 1024;
+}
+
 bool sg_runs32_supported(const SgParams& sg, int32_t L, int32_t S, int32_t bl_start, int32_t bl_end, bool fused_bl) {
     if (!sg.int_ok || sg.W < 5 || sg.W > 11 || !(sg.W & 1)) return false;
     if (S % kSpl != 0 || S - L < 0 || S - L >= kSpl || L < 64) return false;
@@ -581,7 +619,7 @@ hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs&
     if (g < 1) g = 1;
     if (g > resident) g = resident;
     const int grid = (int)g;
-    const size_t dyn = (size_t)kRunsWaves * a.rs * a.wstride * sizeof(uint32_t);  // <= 4 x 8.5 KiB
+    const size_t dyn = (size_t)kRunsWaves * sg_runs32_lds_words(a.rs, a.wstride, a.dep != 0) * sizeof(uint32_t);
 #define WFA_RUNS32(WW)                                                                                           \
     case WW:                                                                                                     \
         if (fused_baseline) hipLaunchKernelGGL((k_sg_runs32<WW, 40>), dim3(grid), dim3(kRunsBlock), dyn, st, a); \

@@ -564,9 +564,9 @@ class DeviceSession:
         _lib.check(self._lib.wfa_last_h2d_rate(self._h, C.byref(v)))
         return float(v.value)
 
-    def set_option(self, name: str, value: bool = True) -> None:
+    def set_option(self, name: str, value: bool | int = True) -> None:
         """Select between code paths with identical results (wfa_set_option: tests and measurement only)."""
-        _lib.check(self._lib.wfa_set_option(self._h, name.encode(), int(bool(value))))
+        _lib.check(self._lib.wfa_set_option(self._h, name.encode(), int(value)))
 
     # -- measurement ----------------------------------------------------------------------------
     def profile(self, on: bool = True) -> None:
