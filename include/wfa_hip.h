@@ -280,6 +280,16 @@ int wfa_group_hit_windows_count(wfa_ctx* ctx, int64_t n_hits, const int64_t* tim
 int wfa_group_hit_windows_fill(wfa_ctx* ctx, int64_t n_hits, int64_t n_events, int64_t* order, int64_t* event_start,
                                int64_t* t_min, int64_t* t_max);
 
+/* Legacy fixed-window grouping: group_multi_channel_hits (processing/event_grouping.py:98-283) with the boundary search of
+ * _find_cluster_boundaries_numba (475-525).  The hits are ordered by timestamp (stable; pandas' default sort leaves the
+ * order of equal timestamps unspecified), a cluster takes every hit whose timestamp is <= (double)first + time_window_ps
+ * (float64 comparison, as numpy / numba compare an int64 column with a float64 needle), and inside a cluster the hits
+ * stand by channel (stable).  order[k] = input row of output row k (event-major); bounds[e] .. bounds[e + 1] = the rows of
+ * event e in `order`.  time_window_ps = time_window_ns * 1e3, formed by the caller as the reference forms it. */
+int wfa_group_multi_channel_count(wfa_ctx* ctx, int64_t n_hits, const int64_t* timestamp, const int64_t* channel,
+                                  double time_window_ps, int64_t* n_events);
+int wfa_group_multi_channel_fill(wfa_ctx* ctx, int64_t n_hits, int64_t n_events, int64_t* order, int64_t* bounds);
+
 /* ---- records builder (reference: processing/records_builder.py) -------------------------------------------------
  * K12 global record order: np.lexsort((seq, channel, board, pid, timestamp)) (records_builder.py:115-120), i.e. the
  * order a k-way merge of sorted parts produces (341-426, 869-945).  order[k] = source row of output row k. */

@@ -32,11 +32,10 @@ def test_find_hits_oracle():
     assert len(case["hits_i16"]) > 60 and len(case["hits_f32"]) > 60
 
 
-@pytest.mark.parametrize("tw", [100, 40])
-def test_group_multi_channel_hits(tw):
+def check_multi_channel_fixture(tw, session):
     case = load()
     df = frame(case)
-    g = group_multi_channel_hits(df, float(tw))
+    g = group_multi_channel_hits(df, float(tw), session=session)
     assert list(g.columns) == MULTI_CHANNEL_COLUMNS
     tag = f"w{tw}"
     np.testing.assert_array_equal(g["t_min"].to_numpy(np.int64), case[f"{tag}_t_min"])
@@ -51,24 +50,61 @@ def test_group_multi_channel_hits(tw):
     np.testing.assert_array_equal([e[0] for e in events], g["t_min"])
 
 
-def test_group_multi_channel_hits_ties_and_edges():
+@pytest.mark.parametrize("tw", [100, 40])
+def test_group_multi_channel_hits(tw):
+    check_multi_channel_fixture(tw, session=False)   # the host table code
+
+
+def check_multi_channel_ties(session):
     rng = np.random.default_rng(4)
     n = 5000
     ts = rng.integers(0, 2000, n) * 1000          # many equal timestamps
     ch = rng.integers(0, 4, n)                      # many equal channels per event
     df = pd.DataFrame({"timestamp": ts, "channel": ch, "charge": rng.uniform(0, 1, n), "peak": rng.uniform(0, 1, n)})
-    g = group_multi_channel_hits(df, 3.0)
+    g = group_multi_channel_hits(df, 3.0, session=session)
     events = O.group_multi_channel_hits_literal(ts, ch, df["charge"].to_numpy(), df["peak"].to_numpy(), 3.0)
     assert len(events) == len(g)
     for (t0, t1, members), (_, row) in zip(events, g.iterrows()):
         np.testing.assert_array_equal(row["timestamps"], ts[members])
         np.testing.assert_array_equal(row["areas"], df["charge"].to_numpy()[members])
         assert (row["t_min"], row["t_max"]) == (t0, t1)
-    assert len(group_multi_channel_hits(df.iloc[:0], 3.0)) == 0
+    assert len(group_multi_channel_hits(df.iloc[:0], 3.0, session=session)) == 0
     with pytest.raises(KeyError, match="area/height"):
-        group_multi_channel_hits(df.drop(columns=["peak"]), 3.0)
+        group_multi_channel_hits(df.drop(columns=["peak"]), 3.0, session=session)
+    with pytest.raises(ValueError, match="time_window_ns"):
+        group_multi_channel_hits(df, -1.0, session=session)
+
+
+def test_group_multi_channel_hits_ties_and_edges():
+    check_multi_channel_ties(session=False)
     np.testing.assert_array_equal(find_cluster_boundaries(np.array([0, 5, 10, 11, 30]), 10.0), [0, 3, 4, 5])
     np.testing.assert_array_equal(find_cluster_boundaries(np.zeros(0), 10.0), [0])
+
+
+@pytest.mark.gpu
+def test_group_multi_channel_hits_gpu():
+    """The device route (two stable radix sorts + the window chain by pointer jumping) against the reference's fixture, the
+    literal oracle, and the host table code on tables that stress the chain: one long cluster, clusters of one hit, a
+    window of zero, timestamps beyond 2^53 (float64 comparison), negative channels."""
+    from waveformanalysis_amd.device import DeviceSession
+    from waveformanalysis_amd.event_grouping import _group_multi_channel_order_host
+
+    with DeviceSession(0) as sess:
+        for tw in (100, 40):
+            check_multi_channel_fixture(tw, session=sess)
+        check_multi_channel_ties(session=sess)
+        rng = np.random.default_rng(11)
+        for n, spread, w_ps in ((1, 10, 5.0), (2, 10, 0.0), (70_000, 50, 1e9), (70_000, 10**9, 3.0), (300_001, 4000, 2500.0),
+                                (300_001, 4000, 0.0), (1000, 3, 1.5)):
+            ts = np.sort(rng.integers(0, max(2, n * spread), n)).astype(np.int64)
+            if n == 1000:
+                ts += (1 << 60)                                   # float64 cannot tell neighbours apart up here
+            rng.shuffle(ts)
+            ch = rng.integers(-3, 40, n).astype(np.int32)
+            order, bounds = sess.group_multi_channel(ts, ch, w_ps)
+            want_order, want_bounds = _group_multi_channel_order_host(ts, ch, w_ps)
+            np.testing.assert_array_equal(bounds, want_bounds, err_msg=f"n {n} window {w_ps}")
+            np.testing.assert_array_equal(order, want_order, err_msg=f"n {n} window {w_ps}")
 
 
 @pytest.mark.gpu

@@ -66,6 +66,8 @@ SIGNATURES = {
     "wfa_hit_merge_emit": (_int, [_p, _i64] + [_p] * 6 + [_i64, _p, _i64, _p] + [_p] * 6),
     "wfa_group_hit_windows_count": (_int, [_p, _i64] + [_p] * 10 + [_f64, C.POINTER(_i64)]),
     "wfa_group_hit_windows_fill": (_int, [_p, _i64, _i64] + [_p] * 4),
+    "wfa_group_multi_channel_count": (_int, [_p, _i64, _p, _p, _f64, C.POINTER(_i64)]),
+    "wfa_group_multi_channel_fill": (_int, [_p, _i64, _i64, _p, _p]),
     "wfa_v1725_index": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64)]),
     "wfa_records_sort": (_int, [_p, _i64, _p, _p, _p, _p, _p]),
     "wfa_pool_gather": (_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _i64]),

@@ -152,7 +152,7 @@ struct wfa_ctx {
     int64_t gathered_n = -1;
     bool gather_append = false;  // wfa_rccl_gather_append: exchanges add to the gathered table instead of replacing it
     int64_t ht_n = -1, ht_groups = 0;
-    int ht_kind = 0;  // 1 = event grouping, 2 = hit merge
+    int ht_kind = 0;  // 1 = event grouping, 2 = hit merge, 3 = legacy multi-channel grouping
     int64_t* ht_perm = nullptr;
     // padded device layout for uniform records whose length is not a multiple of 16 samples (the span16 kernels need
     // every lane's 16-sample chunk inside one record): a shadow copy of the u16 pool with the records at stride

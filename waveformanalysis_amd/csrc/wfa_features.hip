@@ -88,6 +88,9 @@ constexpr int kFwWaves = kFwBlock / kWave;
 constexpr int kFwMaxChunks = 16;   // 16-byte chunks per lane: staged group (<= 8192 samples per wave), leaf (<= 128 samples)
 constexpr int kFwGroupSamples = 8192;
 constexpr int kFwCUs = 256;  // MI355X
+#ifndef WFA_FW_OCC
+#define WFA_FW_OCC 2
+#endif
 
 typedef unsigned short fw_us2 __attribute__((ext_vector_type(2)));
 typedef uint32_t fw_u4 __attribute__((ext_vector_type(4)));
@@ -338,7 +341,7 @@ struct FwCold {  // columns that are only copied into the row: loaded at the end
 // A wave takes a group of 64 >> gl_shift consecutive records; lane = (record of the group, leaf of the reduction).
 // PFN: 16-byte chunks a lane stages per group (13 covers 8 records of up to 832 samples).
 template <int MODE, int PFN>
-__global__ __launch_bounds__(kFwBlock, 2) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
+__global__ __launch_bounds__(kFwBlock, WFA_FW_OCC) void k_features_leaf(FwParams fw, RecView rec, const PwPlan* __restrict__ plan_g,
                                                             uint8_t* __restrict__ out, uint8_t* __restrict__ out2) {
     constexpr bool DO_B = MODE != 1, DO_W = MODE != 0;
     __shared__ PwPlan plan;

@@ -324,6 +324,52 @@ __global__ void k_event_minmax(int64_t n_events, const int64_t* __restrict__ eve
 }
 
 // ---- hit merge --------------------------------------------------------------------------------------------
+// ---- legacy fixed-window grouping (group_multi_channel_hits, event_grouping.py:98-283, 475-525) ----------------------
+// After a stable sort by timestamp a cluster takes every hit within `window` of its FIRST hit: the boundaries are the
+// chain 0 -> next[0] -> next[next[0]] -> ... with next[i] = upper_bound(ts, ts[i] + window), compared in float64 like
+// numpy's searchsorted of an int64 column against a float64 needle.  The chain is marked by pointer jumping: with
+// J_k = next^(2^k), after the levels K-1 .. k the marks are { next^m(0) : 2^k | m }; a level is one launch over all hits.
+__global__ void k_mc_keys(int64_t n, const int64_t* __restrict__ ts, const int64_t* __restrict__ ch,
+                          uint64_t* __restrict__ k_ts, uint64_t* __restrict__ k_ch) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) { k_ts[i] = ord_i64(ts[i]); k_ch[i] = ord_i64(ch[i]); }
+}
+__global__ void k_mc_sorted_ts(int64_t n, const int64_t* __restrict__ ts, const int64_t* __restrict__ perm,
+                               double* __restrict__ ts_f) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n) ts_f[i] = (double)ts[perm[i]];
+}
+__global__ void k_mc_next(int64_t n, const double* __restrict__ ts_f, double window_ps, int32_t* __restrict__ nxt) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { nxt[n] = (int32_t)n; return; }
+    const double needle = ts_f[i] + window_ps;
+    int64_t lo = i + 1, hi = n;  // ts_f[i] <= needle (window >= 0, or NaN: then nothing is <= needle and the cluster is the hit alone)
+    if (!(ts_f[i] <= needle)) { nxt[i] = (int32_t)(i + 1); return; }
+    while (lo < hi) {  // first j in (i, n] with ts_f[j] > needle
+        const int64_t mid = (lo + hi) >> 1;
+        if (ts_f[mid] <= needle) lo = mid + 1; else hi = mid;
+    }
+    nxt[i] = (int32_t)lo;
+}
+__global__ void k_mc_jump(int64_t n, const int32_t* __restrict__ j_in, int32_t* __restrict__ j_out) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i <= n) j_out[i] = j_in[j_in[i]];
+}
+__global__ void k_mc_mark(int64_t n, const int32_t* __restrict__ j_k, int64_t* __restrict__ mark) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n && mark[i]) {
+        const int32_t t = j_k[i];
+        if (t < n) mark[t] = 1;  // (a mark set during this launch belongs to the level's result as well)
+    }
+}
+__global__ void k_mc_bounds(int64_t n, const int64_t* __restrict__ mark, const int64_t* __restrict__ incl, int64_t n_events,
+                            int64_t* __restrict__ bounds) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i < n && mark[i]) bounds[incl[i] - 1] = i;
+    if (i == n - 1) bounds[n_events] = n;
+}
+
 __global__ void k_merge_gather(int64_t n, const int64_t* __restrict__ perm, const double* __restrict__ abs0,
                                const double* __restrict__ abs1, const int32_t* __restrict__ dt,
                                const uint64_t* __restrict__ k_chan, double* __restrict__ s0, double* __restrict__ s1,
@@ -770,6 +816,85 @@ int wfa_group_hit_windows_fill(wfa_ctx* c, int64_t n, int64_t n_events, int64_t*
     WFA_HIP_CHECK(hipMemcpyAsync(event_start, c->ht[S_OUT0].ptr, (size_t)(n_events + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipMemcpyAsync(t_min, c->ht[S_OUT1].ptr, (size_t)n_events * 8, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipMemcpyAsync(t_max, c->ht[S_OUT2].ptr, (size_t)n_events * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return WFA_OK;
+}
+
+int wfa_group_multi_channel_count(wfa_ctx* c, int64_t n, const int64_t* timestamp, const int64_t* channel,
+                                  double time_window_ps, int64_t* n_events) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (n < 0 || !n_events) return fail(WFA_E_INVALID, "bad arguments");
+    c->ht_n = -1;
+    if (n == 0) { c->ht_n = 0; c->ht_groups = 0; c->ht_kind = 3; *n_events = 0; return WFA_OK; }
+    if (!timestamp || !channel) return fail(WFA_E_INVALID, "null column");
+    if (n >= 0x7fffffffLL) return fail(WFA_E_LIMIT, "hit table has %lld rows; the device stages handle < 2^31 - 1", (long long)n);
+    int levels = 1;
+    while ((1ll << levels) < n) ++levels;  // next^(2^levels) of any hit is n
+    int64_t *ts, *ch, *mark, *incl;
+    uint64_t *k_ts, *k_ch, *k_ev;
+    double* ts_f;
+    int32_t* jump;
+    if ((rc = upload(c, S_TS, timestamp, n, &ts)) || (rc = upload(c, S_POS, channel, n, &ch)) ||
+        (rc = slot(c, S_K0, n, &k_ts)) || (rc = slot(c, S_K1, n, &k_ch)) || (rc = slot(c, S_K2, n, &k_ev)) ||
+        (rc = slot(c, S_ABS0, n, &ts_f)) || (rc = slot(c, S_FLAG, n, &mark)) || (rc = slot(c, S_ID, n, &incl)) ||
+        (rc = slot(c, S_OUT3, (int64_t)levels * (n + 1), &jump)))
+        return rc;
+    LaunchTimer t(c);
+    hipLaunchKernelGGL(k_mc_keys, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, ts, ch, k_ts, k_ch);
+    int64_t* perm = nullptr;
+    {
+        const uint64_t* keys[1] = {k_ts};  // df.sort_values("timestamp"), stable
+        if ((rc = lexsort(c, n, keys, 1, &perm))) return rc;
+    }
+    hipLaunchKernelGGL(k_mc_sorted_ts, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, ts, perm, ts_f);
+    hipLaunchKernelGGL(k_mc_next, dim3(blocks_for(n + 1)), dim3(kTB), 0, c->stream, n, ts_f, time_window_ps, jump);
+    for (int k = 1; k < levels; ++k)
+        hipLaunchKernelGGL(k_mc_jump, dim3(blocks_for(n + 1)), dim3(kTB), 0, c->stream, n, jump + (int64_t)(k - 1) * (n + 1),
+                           jump + (int64_t)k * (n + 1));
+    WFA_HIP_CHECK(hipMemsetAsync(mark, 0, (size_t)n * sizeof(int64_t), c->stream));
+    const int64_t one = 1;
+    WFA_HIP_CHECK(hipMemcpyAsync(mark, &one, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    for (int k = levels - 1; k >= 0; --k)
+        hipLaunchKernelGGL(k_mc_mark, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, jump + (int64_t)k * (n + 1), mark);
+    size_t tb = 0;
+    WFA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tb, mark, incl, (size_t)n, rocprim::plus<int64_t>(), c->stream));
+    if ((rc = c->ht[S_CUB].ensure(tb))) return rc;
+    tb = c->ht[S_CUB].cap;
+    WFA_HIP_CHECK(rocprim::inclusive_scan(c->ht[S_CUB].ptr, tb, mark, incl, (size_t)n, rocprim::plus<int64_t>(), c->stream));
+    int64_t n_ev = 0;
+    WFA_HIP_CHECK(hipMemcpyAsync(&n_ev, incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(k_event_keys, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, perm, incl, k_ev);
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));  // (`one` and n_ev live on this stack frame)
+    int64_t* bounds;
+    if ((rc = slot(c, S_OUT0, n_ev + 1, &bounds))) return rc;
+    hipLaunchKernelGGL(k_mc_bounds, dim3(blocks_for(n)), dim3(kTB), 0, c->stream, n, mark, incl, n_ev, bounds);
+    {
+        // inside a cluster by channel, equal channels in timestamp order: np.lexsort((arange, channel, event)) of the sorted
+        // table = a stable sort of the timestamp order by (event, channel)
+        const uint64_t* keys[2] = {k_ev, k_ch};
+        if ((rc = lexsort(c, n, keys, 2, &perm, perm))) return rc;
+    }
+    WFA_HIP_CHECK(hipGetLastError());
+    if ((rc = t.end("hit table: group_multi_channel_hits (sort + pointer jumping)"))) return rc;
+    WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->ht_n = n; c->ht_groups = n_ev; c->ht_kind = 3; c->ht_perm = perm;
+    *n_events = n_ev;
+    return WFA_OK;
+}
+
+int wfa_group_multi_channel_fill(wfa_ctx* c, int64_t n, int64_t n_events, int64_t* order, int64_t* bounds) {
+    int rc = use_device_ht(c);
+    if (rc) return rc;
+    if (c->ht_n < 0 || c->ht_kind != 3) return fail(WFA_E_STATE, "no multi-channel grouping pass has been run");
+    if (n != c->ht_n || n_events != c->ht_groups)
+        return fail(WFA_E_INVALID, "caller expects %lld hits / %lld events, the pass produced %lld / %lld", (long long)n,
+                    (long long)n_events, (long long)c->ht_n, (long long)c->ht_groups);
+    if (!bounds) return fail(WFA_E_INVALID, "bounds is null");
+    if (n == 0) { bounds[0] = 0; return WFA_OK; }
+    if (!order) return fail(WFA_E_INVALID, "order is null");
+    WFA_HIP_CHECK(hipMemcpyAsync(order, c->ht_perm, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    WFA_HIP_CHECK(hipMemcpyAsync(bounds, c->ht[S_OUT0].ptr, (size_t)(n_events + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     WFA_HIP_CHECK(hipStreamSynchronize(c->stream));
     return WFA_OK;
 }

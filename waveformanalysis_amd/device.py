@@ -488,6 +488,21 @@ class DeviceSession:
                                                         _ptr(out["t_min"]), _ptr(out["t_max"])))
         return out
 
+    def group_multi_channel(self, timestamp, channel, time_window_ps: float) -> tuple[np.ndarray, np.ndarray]:
+        """Legacy fixed-window grouping (group_multi_channel_hits): (order, bounds) -- input rows event-major, by channel
+        inside an event; event e = order[bounds[e]:bounds[e + 1]]."""
+        ts = np.ascontiguousarray(timestamp, dtype=np.int64)
+        ch = np.ascontiguousarray(channel, dtype=np.int64)
+        if ts.shape != ch.shape or ts.ndim != 1:
+            raise ValueError("timestamp and channel must be one-dimensional and of equal length")
+        n = int(ts.size)
+        m = C.c_int64(0)
+        _lib.check(self._lib.wfa_group_multi_channel_count(self._h, n, _ptr(ts), _ptr(ch), float(time_window_ps), C.byref(m)))
+        k = int(m.value)
+        order, bounds = np.empty(n, np.int64), np.empty(k + 1, np.int64)
+        _lib.check(self._lib.wfa_group_multi_channel_fill(self._h, n, k, _ptr(order), _ptr(bounds)))
+        return order, bounds
+
     # ---- the same stages on device-resident THRESHOLD_HIT_DTYPE rows (no host columns in, none needed out) ------------
     def hit_rows_source(self, which: str = "hits") -> None:
         """Rows the *_resident stages read: "hits" = the last hit pass of this session, "gather" = the rows the last

@@ -203,31 +203,43 @@ def find_cluster_boundaries(ts_sorted: np.ndarray, time_window_ps: float) -> np.
 MULTI_CHANNEL_COLUMNS = ["event_id", "t_min", "t_max", "dt/ns", "n_hits", "channels", "areas", "heights", "timestamps"]
 
 
-def group_multi_channel_hits(df, time_window_ns: float, use_numba: bool = True, n_processes: int | None = None):
+def group_multi_channel_hits(df, time_window_ns: float, use_numba: bool = True, n_processes: int | None = None,
+                             session=None):
     """Legacy DataFrame grouping (event_grouping.py:98-283): sort by timestamp, fixed windows from each cluster's
-    first hit, members ordered by channel.  Table glue on the host; `use_numba` / `n_processes` are accepted and
-    ignored.  The reference sorts with pandas' / numpy's default (unstable) kinds, so the order of equal
-    timestamps, and of equal channels inside an event, is unspecified there; here both sorts are stable."""
+    first hit, members ordered by channel.  `use_numba` / `n_processes` are accepted and ignored.  The reference sorts
+    with pandas' / numpy's default (unstable) kinds, so the order of equal timestamps, and of equal channels inside an
+    event, is unspecified there; here both sorts are stable.
+
+    Integer timestamp and channel columns go through the device (wfa_group_multi_channel_*: two stable radix sorts, the
+    window chain by pointer jumping); `session=False`, or any other column type, keeps the host table code
+    (`_group_multi_channel_order_host`), which is also what the device result is tested against."""
     import pandas as pd
 
+    if not time_window_ns >= 0:  # (the reference's boundary loop does not terminate for a negative window)
+        raise ValueError("time_window_ns must be >= 0")
     time_window_ps = time_window_ns * 1e3
-    df_sorted = df.sort_values("timestamp", kind="stable").reset_index(drop=True)
-    area_col = "area" if "area" in df_sorted.columns else "charge"
-    height_col = "height" if "height" in df_sorted.columns else "peak"
-    if area_col not in df_sorted.columns or height_col not in df_sorted.columns:
+    area_col = "area" if "area" in df.columns else "charge"
+    height_col = "height" if "height" in df.columns else "peak"
+    if area_col not in df.columns or height_col not in df.columns:
         raise KeyError("df must contain area/height (or charge/peak) columns")
-    ts_all = df_sorted["timestamp"].to_numpy()
-    ch_all = df_sorted["channel"].to_numpy()
-    area_all = df_sorted[area_col].to_numpy()
-    height_all = df_sorted[height_col].to_numpy()
-    n = len(df_sorted)
+    n = len(df)
     if n == 0:
         return pd.DataFrame(columns=MULTI_CHANNEL_COLUMNS)
-    bounds = find_cluster_boundaries(ts_all, time_window_ps)
+    ts_in = df["timestamp"].to_numpy()
+    ch_in = df["channel"].to_numpy()
+    on_device = session is not False and ts_in.dtype.kind in "iu" and ch_in.dtype.kind in "iu" and \
+        ts_in.dtype != np.uint64 and ch_in.dtype != np.uint64
+    if on_device:
+        if session is None:
+            from .device import default_pool
+
+            session = default_pool().session()
+        order, bounds = session.group_multi_channel(ts_in, ch_in, float(time_window_ps))
+    else:
+        order, bounds = _group_multi_channel_order_host(ts_in, ch_in, time_window_ps)
+    ts_o, ch_o = ts_in[order], ch_in[order]
+    ar_o, he_o = df[area_col].to_numpy()[order], df[height_col].to_numpy()[order]
     n_events = len(bounds) - 1
-    event_of = np.repeat(np.arange(n_events), np.diff(bounds))
-    order = np.lexsort((np.arange(n), ch_all, event_of))  # per event: by channel, stable
-    ts_o, ch_o, ar_o, he_o = ts_all[order], ch_all[order], area_all[order], height_all[order]
     starts, ends = bounds[:-1], bounds[1:]
     t_min = ts_o[starts].astype(np.int64)       # the reference takes the first / last row AFTER the channel sort
     t_max = ts_o[ends - 1].astype(np.int64)
@@ -243,6 +255,19 @@ def group_multi_channel_hits(df, time_window_ns: float, use_numba: bool = True, 
         "heights": np.split(he_o, split),
         "timestamps": np.split(ts_o, split),
     })
+
+
+def _group_multi_channel_order_host(ts_in: np.ndarray, ch_in: np.ndarray, time_window_ps: float):
+    """(order, bounds) of group_multi_channel_hits with numpy: stable sort by timestamp, window chain, stable sort by
+    (event, channel)."""
+    n = len(ts_in)
+    by_ts = np.argsort(ts_in, kind="stable")
+    ts_all = ts_in[by_ts]
+    bounds = find_cluster_boundaries(ts_all, time_window_ps)
+    n_events = len(bounds) - 1
+    event_of = np.repeat(np.arange(n_events), np.diff(bounds))
+    inner = np.lexsort((np.arange(n), ch_in[by_ts], event_of))  # per event: by channel, stable
+    return by_ts[inner], np.asarray(bounds, dtype=np.int64)
 
 
 __all__ = ["group_hit_windows", "group_hit_windows_flat", "EVENT_COLUMNS", "find_hits", "find_cluster_boundaries",
