@@ -2334,26 +2334,35 @@ __device__ __forceinline__ void stream_det(const SigT& S, int i_start, const F& 
     bool have_carry = false, active = true;
     int64_t c = (S.off0 + k0) >> 3;
     const int64_t c_lo = S.off0 >> 3, c_hi = (S.off0 + S.L - 1) >> 3;
-    auto consume = [&](int64_t cq, const float (&wf)[8]) __attribute__((always_inline)) {
+    auto consume_some = [&](int64_t cq, const float (&wf)[8], auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;  // every sample of the chunk is part of the walk
         const int kb = (int)(cq * 8 - S.off0);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = DIR > 0 ? jj : 7 - jj;
             const int k = kb + j;
-            const bool in = DIR > 0 ? (k >= k0 && k < S.L) : (k <= k0 && k >= 0);  // false for a chunk outside the record
+            const bool in = FULL || (DIR > 0 ? (k >= k0 && k < S.L) : (k <= k0 && k >= 0));  // false for a chunk outside the record
             if (active && in) {
                 const float w = wf[j];
                 if (!deriv) {
                     active = visit(k, S.det_of(w, 0.f));
                 } else if (DIR > 0) {
-                    if (have_carry) active = visit(k - 1, S.det_of(carry, w));
+                    if (FULL || have_carry) active = visit(k - 1, S.det_of(carry, w));
                     carry = w; have_carry = true;
                 } else {
-                    if (have_carry) active = visit(k, S.det_of(w, carry));
+                    if (FULL || have_carry) active = visit(k, S.det_of(w, carry));
                     carry = w; have_carry = true;
                 }
             }
         }
+    };
+    // Records that start and end on chunk boundaries (every uniform layout) have a partial chunk only where the walk
+    // begins: from the second step on no sample needs its range test (`full` is then true in every lane of the wave)
+    auto consume = [&](int64_t cq, const float (&wf)[8]) __attribute__((always_inline)) {
+        const int kb = (int)(cq * 8 - S.off0);
+        const bool full = (!deriv || have_carry) && (DIR > 0 ? (kb >= k0 && kb + 7 < S.L) : (kb + 7 <= k0 && kb >= 0));
+        if (__ballot(active && !full) == 0) consume_some(cq, wf, std::true_type{});
+        else consume_some(cq, wf, std::false_type{});
     };
     // Two chunks (16 samples) per step, the next two requested before these are consumed: every step of this walk used to
     // wait for its own cache line, and a launch of k_peak_eval is as long as its longest chain of such waits (all of its
