@@ -135,3 +135,38 @@ def test_full_chunk_features(chunk):
     k = 20_000
     G.assert_struct_equal(bf[:k], O.basic_features(rec[:k], pool[: k * 800]), what="basic features prefix vs oracle (bit-exact)")
     G.assert_struct_equal(wi[:k], O.width_integral(rec[:k], pool[: k * 800], dt=2.0), what="width integral prefix vs oracle (bit-exact)")
+
+
+def test_full_chunk_find_peaks(chunk):
+    """The find_peaks hit detector over the filtered 1e9-sample pool (reference defaults: derivative, height 30).
+
+    * three candidate routes -- the height prefilter (default), the plateau machine over every sample (`no_peak_hot`) and the
+      lane-per-record walk of arbitrary layouts (`no_span`) -- give byte-identical rows;
+    * order and range: rows in (record, position) order, positions inside the record, edge_start <= position <= edge_end;
+    * restriction: a prefix uploaded alone gives the first rows of the full result; the oracle on a prefix, bit for bit.
+    """
+    rec, _rec_in, pool = chunk
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+        sess.upload_records(rec, 10.0)
+        sess.savgol(download=False)
+        sess.profile(True)
+        rows = sess.find_peaks(_lib.SRC_F32)
+        assert "k_find_peaks_hot" in sess.profile_report()
+        assert len(rows) > 400_000
+        rid = rows["record_id"]
+        assert np.all(np.diff(rid) >= 0)
+        assert np.all(np.diff(rows["position"])[np.diff(rid) == 0] > 0)
+        assert np.all((rows["position"] >= 0) & (rows["position"] < 799))
+        assert np.all((rows["edge_start"] <= rows["position"]) & (rows["position"] <= rows["edge_end"]))
+        for opt in ("no_peak_hot", "no_span"):
+            sess.set_option(opt, True)
+            assert sess.find_peaks(_lib.SRC_F32).tobytes() == rows.tobytes(), opt
+            sess.set_option(opt, False)
+        k = 200_003
+        sess.upload_records(rec[:k], 10.0)
+        assert sess.find_peaks(_lib.SRC_F32).tobytes() == rows[rid < k].tobytes()
+    k = 20_000
+    filt = O.filter_wave_pool_uniform(pool[: k * 800], 800)
+    G.assert_struct_equal(rows[rid < k], O.find_peak_hits(rec[:k], filt), what="find_peaks prefix vs oracle (bit-exact)")
