@@ -17,6 +17,10 @@ ranks' hit rows are gathered to rank 0 over RCCL (the event-grouping exchange), 
 there (`group_hit_windows`, 100 ns) without a host round trip; `gather_ok` says whether that exchange completed -- if
 it did not, the line is still printed and the process exits non-zero.
 
+Clock state: W warm-up steps (the first GPU work after setup, timed as `clock_ramp.first_steps_ms_per_step`), then
+`--preheat-steps` untimed queued passes (~100 ms: what the GPU needs to reach its sustained clock from idle -- a handful of
+sub-millisecond warm-up steps does not get it there), then the K timed steps.
+
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit..., plus
   roofline     achieved = (2*N + 29*R + 60*H) bytes / mean duration of the streaming kernel, measured with HIP events
                on the kernel's own stream inside the timed region; peak 8000 GB/s; `frac_pass` = the same bytes over
@@ -51,6 +55,9 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preheat-steps", type=int, default=150,
+                    help="untimed passes queued between the warm-up steps and the timed region: ~100 ms of load, the time "
+                         "the GPU takes to reach its sustained clock from idle (profiles/r03_clock_ramp_probe.txt); 0 = none")
     ap.add_argument("--preset", default="v1725")
     ap.add_argument("--records", type=int, default=1_250_000, help="records per GPU (x800 = 1e9 samples)")
     ap.add_argument("--cpu-records", type=int, default=125_000, help="records in the CPU baseline slice")
@@ -309,8 +316,22 @@ def rank_main(args: argparse.Namespace) -> int:
         if dist is not None:
             dist.barrier()
 
+    # The warm-up steps are the first GPU work after the host-side setup; their time is reported as `first_steps` (cold:
+    # first touches, and a GPU that has idled through synthetic-data generation at a low clock).
+    sync_all()
+    t0 = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    sync_all()
+    first_ms = (time.perf_counter() - t0) / max(args.warmup, 1) * 1e3 if args.warmup > 0 else None
+    # Clock ramp: from idle the GPU needs ~30-50 ms of load to reach its sustained clock -- a 0.7 ms step is 35 % slower
+    # in the first 20 steps after an idle half second than from the 40th on (tools/ramp_probe.py,
+    # profiles/r03_clock_ramp_probe.txt).  A handful of warm-up steps is 3 ms of load, so the passes below bring the GPU
+    # to the state a streaming run is in; they are the same enqueued pass as the timed ones, untimed.
+    for _ in range(max(args.preheat_steps, 0)):
+        step_enqueue()
+    if args.preheat_steps > 0:
+        sess.hits_wait()
     # timed region: HIP events only around the dominant (streaming) kernel -- the roofline figure needs its live
     # duration; event pairs around the small follow-up kernels of a pass cost about what the gaps between them do
     sess.profile(2)
@@ -402,6 +423,11 @@ def rank_main(args: argparse.Namespace) -> int:
 
         hit_rows = sess._fill_hits(n_hits)
         for timed in (False, True):  # first round allocates the scratch buffers, second round is reported
+            if timed and args.preheat_steps > 0:  # the host work above left the GPU idle: same clock state as the timed region
+                sess.profile(False)
+                for _ in range(args.preheat_steps):
+                    step_enqueue()
+                sess.hits_wait()
             sess.profile(timed)
             sess.basic_features(L_.SRC_RAW)
             sess.width_integral(L_.SRC_RAW, dt=4.0)
@@ -520,6 +546,11 @@ def rank_main(args: argparse.Namespace) -> int:
             "kernels_ms": {**{k: round(v[0] / max(v[1], 1), 4) for k, v in prof_all.items()},
                            **{k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}},
             "kernels_ms_note": f"{kname}: HIP events inside the timed region; the others: 3 extra passes after it",
+            "clock_ramp": {"preheat_steps": int(args.preheat_steps),
+                           "first_steps_ms_per_step": None if first_ms is None else round(first_ms, 4),
+                           "note": "first_steps = the warm-up steps, the first GPU work after setup (cold clocks, first "
+                                   "touches, one host round trip per step); preheat_steps untimed passes then bring the GPU to "
+                                   "its sustained clock before the timed region (profiles/r03_clock_ramp_probe.txt)"},
             "other_kernels_ms": extra_ms,
             "setup": {"generate_s": round(gen_s, 2), "h2d_s": round(h2d_s, 3), "h2d_GBps": round(h2d_rate, 2),
                       "h2d_note": "wave_pool through two pinned 32-MiB staging buffers"},
