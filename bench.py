@@ -416,7 +416,7 @@ def rank_main(args: argparse.Namespace) -> int:
             gather["ok"] = gather_ok
 
     # ---- the other kernels of the path on the same chunk, timed once each (not part of the metric) ----------------
-    extra_ms, c3, e2e = {}, None, None
+    extra_ms, c3, e2e, two = {}, None, None, None
     if rank == 0 and not args.no_features and gather_ok:
         from waveformanalysis_amd import _lib as L_
         from waveformanalysis_amd.hit_merge import compute_cluster_rows, compute_merged_rows
@@ -497,6 +497,41 @@ def rank_main(args: argparse.Namespace) -> int:
                    "includes creating the session, its device buffers and the pinned ring"}
         except Exception as exc:  # noqa: BLE001
             e2e = {"error": f"{type(exc).__name__}: {exc}"}
+        # two sessions (= two HIP streams) on this GPU, each queuing passes over its own resident copy of the chunk: the
+        # state the chunk-stream plugin keeps a card in (two sessions per device, streaming.py).  Informational: the
+        # headline and the roofline figure above are one session's.
+        try:
+            import threading
+
+            other = DeviceSession(device_id)
+            other.upload_pool(pool)
+            other.upload_records(rec_in, args.threshold)
+            other.set_sg_plan(11, 2)
+            pair = [sess, other]
+
+            def queue_passes(s, k):
+                for _ in range(k):
+                    s.hits_enqueue(_wfa_lib.SRC_SG_FUSED, (0, synth.BASELINE_SAMPLES), 2, 2)
+
+            def both(k):
+                th = [threading.Thread(target=queue_passes, args=(s, k)) for s in pair]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                return [s.hits_wait() for s in pair]
+
+            both(max(args.preheat_steps, 20))
+            k2 = max(args.steps, 100)
+            t1 = time.perf_counter()
+            counts = both(k2)
+            dt2 = time.perf_counter() - t1
+            two = {"ms_per_pass": round(dt2 / (2 * k2) * 1e3, 4), "value": round(2 * k2 * n_samples / dt2 / 1e9, 1),
+                   "unit": "Gsamples/s", "passes": 2 * k2, "same_rows": bool(counts[0] == counts[1] == n_hits),
+                   "what": "two sessions on one GPU queuing passes at the same time, each over its own resident copy of the chunk"}
+            other.close()
+        except Exception as exc:  # noqa: BLE001
+            two = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -559,6 +594,8 @@ def rank_main(args: argparse.Namespace) -> int:
             out["config3"] = c3
         if e2e:
             out["end_to_end"] = e2e
+        if two:
+            out["two_sessions"] = two
         if gather is not None:
             out["gather_ok"] = gather_ok
             out["gather"] = gather
