@@ -204,7 +204,11 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
     if ((rc = c->run_span_cnt.ensure((size_t)ns * sizeof(int32_t)))) return rc;
     if ((rc = c->run_span_row0.ensure((size_t)ns * sizeof(int64_t)))) return rc;
     if ((rc = c->run_scan_blocks.ensure((size_t)(nb + 1) * sizeof(int64_t)))) return rc;
-    if (c->run_ctrl.cap < 256 + sizeof(RunsCold)) c->run_cold_valid = false;
+    const int64_t n_groups = (ns + 63) / 64;
+    if (c->run_groups.cap < (size_t)n_groups * sizeof(unsigned long long)) c->run_groups_n = 0;  // (a new allocation is not zero)
+    if ((rc = c->run_groups.ensure((size_t)n_groups * sizeof(unsigned long long)))) return rc;
+    if (n_groups > c->run_groups_n) c->run_ctrl_clean = false;  // sums beyond what has ever been cleared
+    if (c->run_ctrl.cap < 256 + sizeof(RunsCold)) { c->run_cold_valid = false; c->run_ctrl_clean = false; }
     if ((rc = c->run_ctrl.ensure(256 + sizeof(RunsCold)))) return rc;
 
     PoolView pvf = pool_view(c);
@@ -217,7 +221,7 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
     }
     RowParams rp{le, re, max_len, sp0.W / 2};
     rp.uni_L = sp.L; rp.uni_S = sp.S == sp.L ? 0 : sp.S; rp.uni_positive = sp.positive ? 1 : 0; rp.uni_off0 = sp.off0;
-    const int64_t* d_total = c->run_scan_blocks.as<int64_t>() + nb;
+    int64_t* d_total = c->run_scan_blocks.as<int64_t>() + nb;
     auto* ctrl = c->run_ctrl.as<unsigned long long>();  // [0] event cursor, [1] flags
 
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -237,7 +241,15 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         rn.flags = reinterpret_cast<int32_t*>(ctrl + 1);
         rn.span_off = c->run_span_off.as<int64_t>();
         rn.span_cnt = c->run_span_cnt.as<int32_t>();
-        WFA_HIP_CHECK(hipMemsetAsync(ctrl, 0, 16, c->stream));
+        rn.group_sum = c->run_groups.as<unsigned long long>();
+        // the control words are cleared by the last kernel of a queued pass (RowParams::pass_ctrl); a memset only when the
+        // pass before did not end that way
+        if (!c->run_ctrl_clean) {
+            WFA_HIP_CHECK(hipMemsetAsync(ctrl, 0, 16, c->stream));
+            WFA_HIP_CHECK(hipMemsetAsync(c->run_groups.ptr, 0, (size_t)n_groups * sizeof(unsigned long long), c->stream));
+            if (n_groups > c->run_groups_n) c->run_groups_n = n_groups;
+        }
+        c->run_ctrl_clean = false;
         RunsArgs ra{};
         ra.pool = pvf.u16; ra.thr = rvf.thr; ra.baseline = rvf.baseline_rw; ra.R = R;
         ra.itab = sp0.itab; ra.den = sp0.den; ra.margin = sp0.margin;
@@ -251,6 +263,7 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         ra.off0 = sp.off0; ra.n_spans = ns;
         ra.ev = rn.ev; ra.ev_cap = rn.ev_cap; ra.cursor = rn.cursor; ra.span_off = rn.span_off; ra.span_cnt = rn.span_cnt;
         ra.flags = rn.flags;
+        ra.group_sum = rn.group_sum;
         ra.cold = reinterpret_cast<const RunsCold*>(ctrl + 32);  // 256 bytes behind the atomically updated words
         {
             // what the float64 reference paths read: a device copy next to the control words, refreshed when it changes
@@ -268,17 +281,10 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
             WFA_HIP_CHECK(launch_sg_runs32(c->stream, fused_bl, ra));
             if ((rc = t.end(fused_bl ? "k_sg_runs32<baseline>" : "k_sg_runs32"))) return rc;
         }
-        {
-            LaunchTimer t(c);
-            WFA_HIP_CHECK(launch_scan(c->stream, rn.span_cnt, ns, c->run_scan_blocks.as<int64_t>(),
-                                      c->run_span_row0.as<int64_t>()));
-            if ((rc = t.end("k_scan(span hit counts)"))) return rc;
-        }
         auto rows = [&](int64_t n_rows) -> int {
             {
                 LaunchTimer t(c);
-                WFA_HIP_CHECK(launch_runs_to_desc(c->stream, rn, ns, sp.rs, c->run_span_row0.as<int64_t>(), rp.cap,
-                                                  c->hit_desc.as<int4>()));
+                WFA_HIP_CHECK(launch_runs_to_desc(c->stream, rn, ns, sp.rs, d_total, rp.cap, c->hit_desc.as<int4>()));
                 if (int r2 = t.end("k_runs_to_desc")) return r2;
             }
             {
@@ -297,19 +303,36 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         };
         int64_t total = 0;
         unsigned long long ctl[2] = {0, 0};
-        if (spec) {
+        if (spec && enqueue_only) {
+            // total, cursor and flags are written to the pinned words by the pass's last kernel, which also clears the
+            // control words for the next pass; nobody waits here
             rp.cap = bound;
             rp.n_dev = d_total;
+            rp.pass_report = c->h_total;
+            rp.pass_ctrl = ctrl;
+            rp.pass_groups = rn.group_sum;
+            rp.pass_n_groups = n_groups;
             if ((rc = rows(bound))) return rc;
-            if (enqueue_only) {  // total, cursor and flags go to the pinned words; nobody waits here
-                WFA_HIP_CHECK(hipMemcpyAsync(c->h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-                WFA_HIP_CHECK(hipMemcpyAsync(c->h_total + 1, ctrl, 16, hipMemcpyDeviceToHost, c->stream));
+            c->run_ctrl_clean = true;
+            {
                 c->pending = true;
                 c->pend = {WFA_SRC_SG_FUSED, fused_bl, bl_start, bl_end, le, re, max_len, bound, true};
                 c->n_hits = -1;
                 *done = true;
                 return WFA_OK;
             }
+        }
+        if (spec) {
+            rp.cap = bound;
+            rp.n_dev = d_total;
+            if ((rc = rows(bound))) return rc;
+        } else {
+            // no speculative row launch (first pass on this context, buffers too small): the host needs the row count
+            // before it can size and launch the rows -- the one case that still scans the span counts
+            LaunchTimer t(c);
+            WFA_HIP_CHECK(launch_scan(c->stream, rn.span_cnt, ns, c->run_scan_blocks.as<int64_t>(),
+                                      c->run_span_row0.as<int64_t>()));
+            if ((rc = t.end("k_scan(span hit counts)"))) return rc;
         }
         WFA_HIP_CHECK(hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         WFA_HIP_CHECK(hipMemcpyAsync(ctl, ctrl, 16, hipMemcpyDeviceToHost, c->stream));
@@ -736,7 +759,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                         &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows, &c->out_rows2,
-                      &c->gathered, &c->pw_plan, &c->fw_ties, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl,
+                      &c->gathered, &c->pw_plan, &c->fw_ties, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl, &c->run_groups,
                       &c->shadow_pool, &c->shadow_off};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ht) b.release();

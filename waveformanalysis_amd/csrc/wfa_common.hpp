@@ -104,7 +104,7 @@ struct wfa_ctx {
     wfa::DevBuf bitmap;         // 1 bit per sample, per-record regions (bm_off)
     wfa::DevBuf hit_desc;       // int4 (record, start, end, k) per hit
     // streaming pass on uniform records (k_sg_runs32): event buffer, per-span tables, control words
-    wfa::DevBuf run_ev, run_span_off, run_span_cnt, run_span_row0, run_scan_blocks, run_ctrl;
+    wfa::DevBuf run_ev, run_span_off, run_span_cnt, run_span_row0, run_scan_blocks, run_ctrl, run_groups;
     // host -> device staging: two pinned buffers; a chunk is copied in (a few host threads) while the previous one is on
     // the wire.  Pageable hipMemcpyAsync of a whole pool depends on the driver's own staging (5 GB/s on one box, 0.03
     // GB/s on another)
@@ -184,6 +184,8 @@ struct wfa_ctx {
     // enqueue-only hit passes (wfa_hits_enqueue / wfa_hits_wait): the row count of the last enqueued pass lands in a
     // pinned host word; the pass's arguments are kept in case it outgrew its speculative row bound and must be redone
     int64_t* h_total = nullptr;
+    int64_t run_groups_n = 0;     // group sums that are known to be zero between passes
+    bool run_ctrl_clean = false;  // the streaming pass's control words were cleared by the previous pass's last kernel
     bool pending = false;
     struct { int source; bool fused_bl; int32_t bl_start, bl_end, le, re, max_len; int64_t bound; bool runs32; } pend{};
 

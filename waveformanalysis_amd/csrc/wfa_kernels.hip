@@ -1124,6 +1124,15 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecV
                                                              const int4* __restrict__ desc, int64_t n_hits,
                                                              int only_flagged, uint8_t* __restrict__ out) {
     const int64_t h = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (rp.pass_report && h == 0) {  // (every earlier kernel of the pass has completed: nothing else touches these words now)
+        rp.pass_report[0] = rp.n_dev ? *rp.n_dev : n_hits;
+        rp.pass_report[1] = (int64_t)rp.pass_ctrl[0];
+        rp.pass_report[2] = (int64_t)rp.pass_ctrl[1];
+        rp.pass_ctrl[0] = 0ull;
+        rp.pass_ctrl[1] = 0ull;
+    }
+    if (rp.pass_groups)
+        for (int64_t q = h; q < rp.pass_n_groups; q += (int64_t)gridDim.x * kBlock) rp.pass_groups[q] = 0ull;
     if (rp.n_dev && *rp.n_dev < n_hits) n_hits = *rp.n_dev;
     if (h >= n_hits) return;
     const int4 d = desc[h];

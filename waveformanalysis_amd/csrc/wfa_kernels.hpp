@@ -89,6 +89,7 @@ struct RunsParams {
     int64_t* span_off;           // [n_spans] first event of the span
     int32_t* span_cnt;           // [n_spans] hits (= events / 2) of the span
     int32_t* flags;              // bit 0: a span outgrew the LDS buffer, bit 1: `ev` too small
+    unsigned long long* group_sum;  // [ceil(n_spans / 64)] hits of 64 consecutive spans (atomic adds of the spans' flushes)
 };
 
 // k_sg_runs32: arguments the tile loop keeps in scalar registers, and (by pointer, device-resident) what only the
@@ -116,6 +117,7 @@ struct RunsArgs {
     int64_t* span_off;
     int32_t* span_cnt;
     int32_t* flags;
+    unsigned long long* group_sum;  // see RunsParams
     const RunsCold* cold;
 };
 
@@ -132,6 +134,13 @@ struct RowParams {
     // needs no per-record loads before its first sample chunk (uni_L = 0: read them from the records table)
     int32_t uni_L = 0, uni_positive = 0, uni_S = 0;  // uni_S: stride in samples (0 = uni_L)
     int64_t uni_off0 = 0;
+    // end of a queued streaming pass (k_hit_rows_literal is its last kernel): one thread copies the pass's row count and the
+    // two control words (event cursor, overflow flags) to `pass_report` (pinned host memory) and clears the control words
+    // for the next pass -- what two device-to-host copies and a memset did as three more launches per pass
+    int64_t* pass_report = nullptr;
+    unsigned long long* pass_ctrl = nullptr;
+    unsigned long long* pass_groups = nullptr;  // the pass's group sums (RunsParams::group_sum), cleared as well
+    int64_t pass_n_groups = 0;
 };
 
 // find_peaks-based hit detector (k_find_peaks): scalar lower bounds only, as the reference plugin passes them
@@ -224,7 +233,7 @@ int64_t sg_runs32_lds_words(int32_t rs, int32_t wstride, bool dep);
 bool sg_runs32_deposit(int32_t L, int32_t S, int32_t W, int32_t rs, int32_t wstride);
 hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs& a);
 hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,
-                               const int64_t* span_row0, int64_t cap, int4* desc);
+                               int64_t* total_out, int64_t cap, int4* desc);
 hipError_t launch_hit_runs(hipStream_t st, const RecView& rec, const uint8_t* bitmap, const int32_t* nhits,
                            const int64_t* out_start, int4* desc, const RowParams& rp);
 // grouped: the 8-lanes-per-hit kernel of rounds 1-2 (wfa_set_option "rows_grouped"); default: the flat chunk-per-lane kernel

@@ -546,6 +546,8 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
             if (lane == 0) {
                 a.span_off[span] = (int64_t)base;
                 a.span_cnt[span] = total >> 1;
+                // hits of 64 consecutive spans: what k_runs_to_desc needs to place a span's rows without a scan launch
+                if (fits) atomicAdd(&a.group_sum[span >> 6], (unsigned long long)(total >> 1));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
@@ -554,15 +556,27 @@ __global__ __launch_bounds__(kRunsBlock, kRunsOcc) void k_sg_runs32(RunsArgs a) 
 
 // events of a span -> hit descriptors (record, start, end, 0) in (record, start) order; one wave per span
 __global__ __launch_bounds__(kBlock) void k_runs_to_desc(RunsParams rp, int64_t n_spans, int32_t rs,
-                                                         const int64_t* __restrict__ span_row0, int64_t cap,
+                                                         int64_t* __restrict__ total_out, int64_t cap,
                                                          int4* __restrict__ desc) {
     const int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (s >= n_spans) return;
-    if (*rp.flags != 0) return;  // overflow: the events are incomplete, the caller redoes the pass
+    const int lane = lane_id();
+    if (*rp.flags != 0) {  // overflow: the events are incomplete, the caller redoes the pass; no rows until then
+        if (s == n_spans - 1 && lane == 0) *total_out = 0;
+        return;
+    }
     const int cnt = rp.span_cnt[s];
+    // first row of the span = hits of all spans in front of it: whole groups of 64 spans from the sums the streaming
+    // kernel's flushes added up, the spans of its own group one per lane (this replaced a three-launch scan of span_cnt)
+    const int64_t g = s >> 6;
+    int64_t acc = 0;
+    for (int64_t q = lane; q < g; q += kWave) acc += (int64_t)rp.group_sum[q];
+    const int64_t sl = (g << 6) + lane;
+    acc += sl < s ? (int64_t)rp.span_cnt[sl] : 0;
+    const int64_t row0 = wave_sum_i64(acc);
+    if (s == n_spans - 1 && lane == 0) *total_out = row0 + cnt;
     const uint2* __restrict__ ev = reinterpret_cast<const uint2*>(rp.ev + rp.span_off[s]);  // event counts are even
-    const int64_t row0 = span_row0[s];
-    for (int k = lane_id(); k < cnt; k += kWave) {
+    for (int k = lane; k < cnt; k += kWave) {
         const uint2 e = ev[k];
         const int64_t row = row0 + k;
         if (cap == 0 || row < cap)
@@ -637,10 +651,10 @@ hipError_t launch_sg_runs32(hipStream_t st, bool fused_baseline, const RunsArgs&
 }
 
 hipError_t launch_runs_to_desc(hipStream_t st, const RunsParams& rp, int64_t n_spans, int32_t rs,
-                               const int64_t* span_row0, int64_t cap, int4* desc) {
+                               int64_t* total_out, int64_t cap, int4* desc) {
     if (n_spans == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n_spans + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(k_runs_to_desc, dim3(grid), dim3(kBlock), 0, st, rp, n_spans, rs, span_row0, cap, desc);
+    hipLaunchKernelGGL(k_runs_to_desc, dim3(grid), dim3(kBlock), 0, st, rp, n_spans, rs, total_out, cap, desc);
     return hipGetLastError();
 }
 
