@@ -64,6 +64,9 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threshold", type=float, default=10.0, help="hit threshold (reference default 10.0)")
     ap.add_argument("--no-features", action="store_true", help="skip the untimed feature / filter / end-to-end extras")
+    ap.add_argument("--two-sessions", action="store_true",
+                    help="also measure two sessions queuing passes on this GPU at the same time (informational; kernels of "
+                         "the two streams overlap, so do not combine with a profiler run whose averages are to be compared)")
     ap.add_argument("--c4-records", type=int, default=333_334,
                     help="N > 1 only: records per GPU of the untimed config-4 leg (256-ch VX2730, x1500 = 5e8 samples); 0 = skip")
     ap.add_argument("--master-port", type=int, default=int(os.environ.get("WFA_BENCH_PORT", "29613")))
@@ -501,6 +504,8 @@ def rank_main(args: argparse.Namespace) -> int:
         # state the chunk-stream plugin keeps a card in (two sessions per device, streaming.py).  Informational: the
         # headline and the roofline figure above are one session's.
         try:
+            if not args.two_sessions:
+                raise LookupError("not requested")
             import threading
 
             other = DeviceSession(device_id)
@@ -530,6 +535,8 @@ def rank_main(args: argparse.Namespace) -> int:
                    "unit": "Gsamples/s", "passes": 2 * k2, "same_rows": bool(counts[0] == counts[1] == n_hits),
                    "what": "two sessions on one GPU queuing passes at the same time, each over its own resident copy of the chunk"}
             other.close()
+        except LookupError:
+            two = None
         except Exception as exc:  # noqa: BLE001
             two = {"error": f"{type(exc).__name__}: {exc}"}
 
