@@ -561,10 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_runs_to_desc(RunsParams rp, int64_t 
     const int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (s >= n_spans) return;
     const int lane = lane_id();
-    if (*rp.flags != 0) {  // overflow: the events are incomplete, the caller redoes the pass; no rows until then
-        if (s == n_spans - 1 && lane == 0) *total_out = 0;
-        return;
-    }
+    const int bad = *rp.flags;  // (tested after the loads below have been issued: one round trip instead of two)
     const int cnt = rp.span_cnt[s];
     // first row of the span = hits of all spans in front of it: whole groups of 64 spans from the sums the streaming
     // kernel's flushes added up, the spans of its own group one per lane (this replaced a three-launch scan of span_cnt)
@@ -574,8 +571,12 @@ __global__ __launch_bounds__(kBlock) void k_runs_to_desc(RunsParams rp, int64_t 
     const int64_t sl = (g << 6) + lane;
     acc += sl < s ? (int64_t)rp.span_cnt[sl] : 0;
     const int64_t row0 = wave_sum_i64(acc);
-    if (s == n_spans - 1 && lane == 0) *total_out = row0 + cnt;
     const uint2* __restrict__ ev = reinterpret_cast<const uint2*>(rp.ev + rp.span_off[s]);  // event counts are even
+    if (bad != 0) {  // overflow: the events are incomplete, the caller redoes the pass; no rows until then
+        if (s == n_spans - 1 && lane == 0) *total_out = 0;
+        return;
+    }
+    if (s == n_spans - 1 && lane == 0) *total_out = row0 + cnt;
     for (int k = lane; k < cnt; k += kWave) {
         const uint2 e = ev[k];
         const int64_t row = row0 + k;
