@@ -222,7 +222,14 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
     RowParams rp{le, re, max_len, sp0.W / 2};
     rp.uni_L = sp.L; rp.uni_S = sp.S == sp.L ? 0 : sp.S; rp.uni_positive = sp.positive ? 1 : 0; rp.uni_off0 = sp.off0;
     int64_t* d_total = c->run_scan_blocks.as<int64_t>() + nb;
-    auto* ctrl = c->run_ctrl.as<unsigned long long>();  // [0] event cursor, [1] flags
+    auto* ctrl = c->run_ctrl.as<unsigned long long>();  // [0] event cursor, [1] flags, [2] hits listed for the literal kernel
+    constexpr int kLitCap = 65536;
+    if ((rc = c->run_lit.ensure((size_t)kLitCap * sizeof(int32_t)))) return rc;
+    if (!c->opt.rows_grouped) {  // (the 8-lanes-per-hit kernel only flags)
+        rp.lit_cnt = reinterpret_cast<uint32_t*>(ctrl + 2);
+        rp.lit_list = c->run_lit.as<int32_t>();
+        rp.lit_cap = kLitCap;
+    }
 
     for (int attempt = 0; attempt < 3; ++attempt) {
         // speculative tail (see run_hits): row buffers sized from the previous pass on this context
@@ -242,6 +249,7 @@ static int run_hits_runs32(wfa_ctx* c, bool fused_bl, int32_t bl_start, int32_t 
         rn.span_off = c->run_span_off.as<int64_t>();
         rn.span_cnt = c->run_span_cnt.as<int32_t>();
         rn.group_sum = c->run_groups.as<unsigned long long>();
+        rn.lit_cnt = c->opt.rows_grouped ? nullptr : reinterpret_cast<uint32_t*>(ctrl + 2);
         // the control words are cleared by the last kernel of a queued pass (RowParams::pass_ctrl); a memset only when the
         // pass before did not end that way
         if (!c->run_ctrl_clean) {
@@ -759,7 +767,7 @@ void wfa_ctx_destroy(wfa_ctx* c) {
                         &c->peak_cand_state, &c->peak_cand_rec, &c->peak_accept, &c->peak_ips, &c->peak_row_start, &c->wh_pos, &c->wh_row, &c->wh_valid, &c->sg.tab,
                       &c->sg.itab, &c->sg.sym, &c->hit_tmp, &c->cursor, &c->rec_tmp_start,
                       &c->rec_nhits, &c->rec_out_start, &c->scan_blocks, &c->hit_out, &c->out_rows, &c->out_rows2,
-                      &c->gathered, &c->pw_plan, &c->fw_ties, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl, &c->run_groups,
+                      &c->gathered, &c->pw_plan, &c->fw_ties, &c->run_ev, &c->run_span_off, &c->run_span_cnt, &c->run_span_row0, &c->run_scan_blocks, &c->run_ctrl, &c->run_groups, &c->run_lit,
                       &c->shadow_pool, &c->shadow_off};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ht) b.release();

@@ -104,7 +104,7 @@ struct wfa_ctx {
     wfa::DevBuf bitmap;         // 1 bit per sample, per-record regions (bm_off)
     wfa::DevBuf hit_desc;       // int4 (record, start, end, k) per hit
     // streaming pass on uniform records (k_sg_runs32): event buffer, per-span tables, control words
-    wfa::DevBuf run_ev, run_span_off, run_span_cnt, run_span_row0, run_scan_blocks, run_ctrl, run_groups;
+    wfa::DevBuf run_ev, run_span_off, run_span_cnt, run_span_row0, run_scan_blocks, run_ctrl, run_groups, run_lit;
     // host -> device staging: two pinned buffers; a chunk is copied in (a few host threads) while the previous one is on
     // the wire.  Pageable hipMemcpyAsync of a whole pool depends on the driver's own staging (5 GB/s on one box, 0.03
     // GB/s on another)

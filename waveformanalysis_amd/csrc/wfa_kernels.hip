@@ -1134,9 +1134,19 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecV
     if (rp.pass_groups)
         for (int64_t q = h; q < rp.pass_n_groups; q += (int64_t)gridDim.x * kBlock) rp.pass_groups[q] = 0ull;
     if (rp.n_dev && *rp.n_dev < n_hits) n_hits = *rp.n_dev;
-    if (h >= n_hits) return;
-    const int4 d = desc[h];
-    if (only_flagged && d.w == 0) return;
+    int64_t hh = h;
+    bool listed = false;
+    if (only_flagged && rp.lit_cnt) {
+        const uint32_t nl = *rp.lit_cnt;
+        if (nl <= (uint32_t)rp.lit_cap) {  // the fast kernel listed every hit it left: no pass over the descriptors' flags
+            if (h >= (int64_t)nl) return;
+            hh = rp.lit_list[h];
+            listed = true;
+        }
+    }
+    if (hh >= n_hits) return;
+    const int4 d = desc[hh];
+    if (only_flagged && !listed && d.w == 0) return;
     const int64_t r = d.x;
     const int start = d.y, end = d.z;
     const int L = rec.len[r];
@@ -1150,7 +1160,7 @@ __global__ __launch_bounds__(kBlock) void k_hit_rows_literal(PoolView pool, RecV
     const int seg_end = end + hc.re < hc.max_len ? end + hc.re : hc.max_len;
     HitAcc acc{-__builtin_huge_val(), 0x7fffffff, 0.0};
     for (int i = seg_start; i < seg_end; ++i) acc.add(hit_signal<SRC>(src, hc, i), i);
-    write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
+    write_hit_row(out, hh, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
 }
 
 // fast path: 8 lanes per hit.  Lane q of a group loads the aligned 16-byte chunk (c + q) and produces its 8 outputs
@@ -1626,8 +1636,15 @@ __global__ __launch_bounds__(kWave) void k_hit_rows_flat(PoolView pool, RecView 
         }
     }
     if (work) {
-        if (need_literal) desc[h].w = 2;  // below the integer guard: the literal kernel redoes this hit
-        else write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
+        if (need_literal) {  // below the integer guard: the literal kernel redoes this hit
+            desc[h].w = 2;
+            if (rp.lit_cnt) {
+                const uint32_t slot = atomicAdd(rp.lit_cnt, 1u);
+                if (slot < (uint32_t)rp.lit_cap) rp.lit_list[slot] = (int32_t)h;
+            }
+        } else {
+            write_hit_row(out, h, rec, r, L, start, end, seg_start, seg_end, acc.best_i, acc.best, acc.sum);
+        }
     }
 }
 

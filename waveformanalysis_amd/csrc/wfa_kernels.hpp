@@ -90,6 +90,7 @@ struct RunsParams {
     int32_t* span_cnt;           // [n_spans] hits (= events / 2) of the span
     int32_t* flags;              // bit 0: a span outgrew the LDS buffer, bit 1: `ev` too small
     unsigned long long* group_sum;  // [ceil(n_spans / 64)] hits of 64 consecutive spans (atomic adds of the spans' flushes)
+    uint32_t* lit_cnt;              // RowParams::lit_cnt (k_runs_to_desc clears it)
 };
 
 // k_sg_runs32: arguments the tile loop keeps in scalar registers, and (by pointer, device-resident) what only the
@@ -141,6 +142,12 @@ struct RowParams {
     unsigned long long* pass_ctrl = nullptr;
     unsigned long long* pass_groups = nullptr;  // the pass's group sums (RunsParams::group_sum), cleared as well
     int64_t pass_n_groups = 0;
+    // hits the fast row kernel hands to the literal kernel, as a list (count cleared by k_runs_to_desc at the start of the
+    // pass): the literal kernel then reads the list instead of every descriptor's flag; more than lit_cap entries -> the
+    // flags decide as before
+    uint32_t* lit_cnt = nullptr;
+    int32_t* lit_list = nullptr;
+    int32_t lit_cap = 0;
 };
 
 // find_peaks-based hit detector (k_find_peaks): scalar lower bounds only, as the reference plugin passes them

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(kBlock) void k_runs_to_desc(RunsParams rp, int64_t 
     if (s >= n_spans) return;
     const int lane = lane_id();
     const int bad = *rp.flags;  // (tested after the loads below have been issued: one round trip instead of two)
+    if (s == 0 && lane == 0 && rp.lit_cnt) *rp.lit_cnt = 0u;  // the list of hits the row kernel hands to the literal kernel
     const int cnt = rp.span_cnt[s];
     // first row of the span = hits of all spans in front of it: whole groups of 64 spans from the sums the streaming
     // kernel's flushes added up, the spans of its own group one per lane (this replaced a three-launch scan of span_cnt)
