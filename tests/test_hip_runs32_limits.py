@@ -204,3 +204,42 @@ def test_edge_samples_from_lds_equal_edge_samples_from_memory(preset, n, L, fuse
         sess.set_option("span_records", 51)     # spans of fewer records than a wave has lanes (measurement option)
         sess.upload_records(up, 10.0)
         assert run().tobytes() == got.tobytes()
+
+
+def test_queued_passes_overflow_regrow_and_control_words():
+    """Queued passes (wfa_hits_enqueue) leave no host round trip between their kernels: the last kernel of a pass writes the
+    row count and the control words to pinned memory and clears control words and group sums for the next pass.  Three
+    ways such a pass has to be redone or followed up: a span overflows its event slot (general route, then recovery), the
+    speculative row launch was sized for fewer rows than the pass finds (exact route), and several queued passes in a row
+    with a plain (waited) pass in between -- rows equal the oracle's every time."""
+    rec, pool = synth.make_run(20_000, "v1725", cfg=5)
+    filt = O.filter_wave_pool(rec, pool)
+    want = {thr: O.threshold_hits_chunked(rec, filt, threshold=thr) for thr in (6.0, 10.0, 40.0)}
+    assert len(want[40.0]) * 1.125 + 4096 < len(want[6.0])          # the speculative launch after the 40.0 pass is too small
+    small = rec[:640]
+    want[1.0] = O.threshold_hits_chunked(small, filt[: 640 * 800], threshold=1.0)
+    with DeviceSession(0) as sess:
+        sess.upload_pool(pool)
+        sess.set_sg_plan(11, 2)
+
+        def queued(thr, n_queue=1):
+            sess.upload_records(small if thr == 1.0 else rec, thr)
+            for _ in range(n_queue):
+                sess.hits_enqueue(_lib.SRC_SG_FUSED, (0, 0), 2, 2)
+            return sess._fill_hits(sess.hits_wait())
+
+        sess.upload_records(rec, 10.0)
+        first = sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2)             # sizes the row buffers: later passes may speculate
+        G.assert_struct_equal(first, want[10.0], float_rtol=1e-6, what="waited pass")
+        G.assert_struct_equal(queued(10.0, 3), want[10.0], float_rtol=1e-6, what="three queued passes")
+        G.assert_struct_equal(queued(40.0), want[40.0], float_rtol=1e-6, what="fewer rows than the last pass")
+        G.assert_struct_equal(queued(6.0), want[6.0], float_rtol=1e-6, what="more rows than the speculative launch held")
+        G.assert_struct_equal(queued(6.0, 2), want[6.0], float_rtol=1e-6, what="queued again after the regrow")
+        sess.profile(True)
+        G.assert_struct_equal(queued(1.0), want[1.0], float_rtol=1e-6, what="a span overflows its event slot")
+        names = sess.profile_report()
+        assert "k_sg_runs32" in names and "k_hit_runs" in names, sorted(names)   # streaming pass, then the bitmap route
+        sess.profile(True)
+        G.assert_struct_equal(queued(10.0, 2), want[10.0], float_rtol=1e-6, what="next upload: streaming route again")
+        assert "k_sg_runs32" in sess.profile_report() and "k_hit_runs" not in sess.profile_report()
+        G.assert_struct_equal(sess.threshold_hits(_lib.SRC_SG_FUSED, 2, 2), want[10.0], float_rtol=1e-6, what="waited pass after queued ones")
