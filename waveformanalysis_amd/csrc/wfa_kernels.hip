@@ -3131,8 +3131,7 @@ __global__ __launch_bounds__(kPeakBlock) void k_peak_eval(PoolView pool, RecView
     // 1.58 ms against 1.21 ms, the walks of neighbouring candidates share cache lines.  Nor did a wave-level form of the
     // walks without a branch per sample -- both directions in one loop, every sample slot evaluated by every lane through
     // selects: identical rows, 0.92 ms against 0.70: 201 registers, 2 waves per SIMD, and the launch is a chain of load
-    // round trips per wave, not instruction issue.  One direction at a time in the same style: 100-108 registers, identical
-    // rows, 1.00 ms against 0.67.)
+    // round trips per wave, not instruction issue.)
     const int64_t k = (int64_t)blockIdx.x * kPeakBlock + threadIdx.x;
     if (k >= n_cand) return;
     int ok = 0;
